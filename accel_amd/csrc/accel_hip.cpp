@@ -1,0 +1,1113 @@
+// libaccel_hip: plan executor + C ABI (see include/accel_hip.h).
+//
+// A plan is the text form of a lowered graph: one fused kernel op per line,
+// `kind key=value ...`.  Buffer references are `space:byteoff:C:Cs:H:W` where
+// space is `A` (the plan's activation arena; offsets assigned by the Python
+// liveness planner) or the name of a model-level persistent buffer.
+// Parameters are referenced by their MXNet names and repacked here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/accel_hip.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail(ACCEL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+extern "C" const char* accel_last_error(void) { return g_err.c_str(); }
+extern "C" const char* accel_version(void) { return "accel_hip 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------
+struct accel_ctx {
+    int device;
+    hipStream_t stream;
+};
+
+struct HostParam {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    size_t numel() const { return data.size(); }
+};
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct accel_model {
+    accel_ctx* ctx;
+    std::map<std::string, HostParam> params;
+    std::map<std::string, DevBuf> pbufs;
+    std::vector<accel_plan*> plans;
+    std::map<std::string, accel_plan*> roles;
+};
+
+struct BufRef {
+    std::string space;
+    size_t off = 0;
+    int C = 0, Cs = 0, H = 0, W = 0;
+    bool set = false;
+    float* ptr = nullptr;   // resolved at finalize
+};
+
+typedef std::map<std::string, std::string> KV;
+
+enum OpKind { OP_PREP_RGB, OP_PREP_FLOW, OP_CONV, OP_POOL, OP_WARP, OP_DCN_COLS, OP_SCORE_TAIL,
+              OP_COPY, OP_EXPORT_NCHW, OP_IMPORT_NCHW };
+
+struct Op {
+    OpKind kind;
+    std::string kind_name, name;
+    KV kv;
+    double flops = 0, bytes = 0;
+    // resolved launch state
+    ConvParams conv;
+    PoolParams pool;
+    DcnColsParams dcn;
+    ScoreTailParams tail;
+    BufRef a, b, c, d;          // generic buffer slots
+    const float* p0 = nullptr;  // generic device param slots
+    const float* p1 = nullptr;
+    size_t nbytes = 0;
+    int H = 0, W = 0;
+};
+
+struct accel_plan {
+    accel_model* m;
+    std::string role;
+    std::vector<Op> ops;
+    size_t arena_bytes = 0;
+    char* arena = nullptr;
+    std::vector<void*> owned;       // packed weights etc.
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool finalized = false;
+    bool allow_graph = true;
+};
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+static int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+static bool kv_has(const KV& kv, const char* k) { return kv.find(k) != kv.end(); }
+static std::string kv_str(const KV& kv, const char* k, const char* def = "")
+{
+    auto it = kv.find(k);
+    return it == kv.end() ? std::string(def) : it->second;
+}
+static long kv_int(const KV& kv, const char* k, long def = 0)
+{
+    auto it = kv.find(k);
+    return it == kv.end() ? def : strtol(it->second.c_str(), nullptr, 10);
+}
+static double kv_f(const KV& kv, const char* k, double def = 0)
+{
+    auto it = kv.find(k);
+    return it == kv.end() ? def : strtod(it->second.c_str(), nullptr);
+}
+static void kv_pair(const KV& kv, const char* k, int& a, int& b, int da, int db)
+{
+    auto it = kv.find(k);
+    a = da; b = db;
+    if (it == kv.end()) return;
+    sscanf(it->second.c_str(), "%d,%d", &a, &b);
+}
+
+static int parse_buf(const KV& kv, const char* key, BufRef& r)
+{
+    auto it = kv.find(key);
+    if (it == kv.end()) { r.set = false; return 0; }
+    std::vector<std::string> f;
+    std::stringstream ss(it->second);
+    std::string tok;
+    while (std::getline(ss, tok, ':')) f.push_back(tok);
+    if (f.size() != 6) return fail(ACCEL_ERR_PLAN, "bad buffer reference %s=%s", key, it->second.c_str());
+    r.space = f[0];
+    r.off = strtoull(f[1].c_str(), nullptr, 10);
+    r.C = atoi(f[2].c_str()); r.Cs = atoi(f[3].c_str()); r.H = atoi(f[4].c_str()); r.W = atoi(f[5].c_str());
+    r.set = true;
+    return 0;
+}
+
+static int dev_upload(accel_plan* p, const void* host, size_t bytes, void** out)
+{
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes ? bytes : 4));
+    if (bytes) HIP_TRY(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    p->owned.push_back(d);
+    *out = d;
+    return 0;
+}
+
+static const HostParam* get_param(accel_model* m, const std::string& name)
+{
+    auto it = m->params.find(name);
+    return it == m->params.end() ? nullptr : &it->second;
+}
+
+// BatchNorm inference folding -- identical expressions to oracle orc_bn_fold
+// (MXNet mshadow inference form): scale = g/sqrt(var+eps), shift = beta - g*mean/sqrt(var+eps)
+static int bn_fold(accel_model* m, const std::string& bn, float eps, int fixg, int C,
+                   std::vector<float>& scale, std::vector<float>& shift)
+{
+    const HostParam* g = get_param(m, bn + "_gamma");
+    const HostParam* b = get_param(m, bn + "_beta");
+    const HostParam* mu = get_param(m, bn + "_moving_mean");
+    const HostParam* var = get_param(m, bn + "_moving_var");
+    if (!b || !mu || !var || (!g && !fixg))
+        return fail(ACCEL_ERR_PARAM, "BatchNorm %s: gamma/beta/moving_mean/moving_var not initialized", bn.c_str());
+    if ((int)b->numel() != C || (int)mu->numel() != C || (int)var->numel() != C)
+        return fail(ACCEL_ERR_PARAM, "BatchNorm %s: expected %d channels, got %zu", bn.c_str(), C, b->numel());
+    scale.assign(C, 0.f); shift.assign(C, 0.f);
+    for (int c = 0; c < C; ++c) {
+        const float gg = fixg ? 1.0f : g->data[c];
+        const float sd = sqrtf(var->data[c] + eps);
+        scale[c] = gg / sd;
+        shift[c] = b->data[c] - (gg * mu->data[c]) / sd;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// plan parsing
+// ---------------------------------------------------------------------------
+static int parse_plan(accel_plan* p, const char* text)
+{
+    std::stringstream ss(text);
+    std::string line;
+    int lineno = 0;
+    while (std::getline(ss, line)) {
+        ++lineno;
+        if (line.empty() || line[0] == '#') continue;
+        std::stringstream ls(line);
+        std::string kind, tok;
+        ls >> kind;
+        KV kv;
+        while (ls >> tok) {
+            size_t eq = tok.find('=');
+            if (eq == std::string::npos) return fail(ACCEL_ERR_PLAN, "line %d: token '%s' is not key=value", lineno, tok.c_str());
+            kv[tok.substr(0, eq)] = tok.substr(eq + 1);
+        }
+        if (kind == "option") { if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0; continue; }
+        if (kind == "arena") { p->arena_bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10); continue; }
+        if (kind == "pbuf") {
+            const std::string name = kv_str(kv, "name");
+            const size_t bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10);
+            if (name.empty() || !bytes) return fail(ACCEL_ERR_PLAN, "line %d: pbuf needs name and bytes", lineno);
+            DevBuf& b = p->m->pbufs[name];
+            if (!b.ptr) {
+                if (hipMalloc(&b.ptr, bytes) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipMalloc(%zu) for pbuf %s failed", bytes, name.c_str());
+                b.bytes = bytes;
+                if (hipMemsetAsync(b.ptr, 0, bytes, p->m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipMemset pbuf failed");   // same stream as later writes: ordered
+            } else if (b.bytes < bytes) {
+                return fail(ACCEL_ERR_PLAN, "pbuf %s already exists with %zu bytes < %zu", name.c_str(), b.bytes, bytes);
+            }
+            continue;
+        }
+        Op op;
+        op.kind_name = kind;
+        op.kv = kv;
+        op.name = kv_str(kv, "name");
+        op.flops = kv_f(kv, "flops");
+        op.bytes = kv_f(kv, "bytes");
+        if (kind == "prep_rgb") op.kind = OP_PREP_RGB;
+        else if (kind == "prep_flow") op.kind = OP_PREP_FLOW;
+        else if (kind == "conv") op.kind = OP_CONV;
+        else if (kind == "pool") op.kind = OP_POOL;
+        else if (kind == "warp") op.kind = OP_WARP;
+        else if (kind == "dcn_cols") op.kind = OP_DCN_COLS;
+        else if (kind == "score_tail") op.kind = OP_SCORE_TAIL;
+        else if (kind == "copy") op.kind = OP_COPY;
+        else if (kind == "export_nchw") op.kind = OP_EXPORT_NCHW;
+        else if (kind == "import_nchw") op.kind = OP_IMPORT_NCHW;
+        else return fail(ACCEL_ERR_PLAN, "line %d: unknown op '%s'", lineno, kind.c_str());
+        p->ops.push_back(op);
+    }
+    return 0;
+}
+
+static int resolve(accel_plan* p, BufRef& r, const char* what)
+{
+    if (!r.set) return fail(ACCEL_ERR_PLAN, "missing buffer '%s'", what);
+    if (r.space == "A") {
+        const size_t need = r.off + (size_t)r.H * r.W * r.Cs * sizeof(float);
+        // a view's last pixel row may stop short of Cs; be lenient by C
+        const size_t need_min = r.off + ((size_t)(r.H * r.W - 1) * r.Cs + r.C) * sizeof(float);
+        (void)need;
+        if (need_min > p->arena_bytes) return fail(ACCEL_ERR_PLAN, "buffer '%s' exceeds arena (%zu > %zu)", what, need_min, p->arena_bytes);
+        r.ptr = reinterpret_cast<float*>(p->arena + r.off);
+    } else {
+        auto it = p->m->pbufs.find(r.space);
+        if (it == p->m->pbufs.end()) return fail(ACCEL_ERR_PLAN, "buffer '%s': unknown persistent buffer '%s'", what, r.space.c_str());
+        r.ptr = reinterpret_cast<float*>(static_cast<char*>(it->second.ptr) + r.off);
+    }
+    if (r.space == "A" && (r.Cs % 4 || (r.off % 16))) return fail(ACCEL_ERR_PLAN, "buffer '%s': Cs %d / offset %zu not 16-byte aligned", what, r.Cs, r.off);
+    return 0;
+}
+
+// ---- weight repacking -------------------------------------------------------
+// conv weights (Cout, Cin, kh, kw) -> [rows][K_pad], k = (ky*kw + kx)*cin_pad + ci
+static void pack_conv_w(const HostParam& w, int cin_pad, int rows, int K_pad, std::vector<float>& out)
+{
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    out.assign((size_t)rows * K_pad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx)
+                    out[(size_t)co * K_pad + (size_t)(ky * kw + kx) * cin_pad + ci] =
+                        w.data[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
+}
+
+// deconv 4x4 s2 p1 weights (Cin, Cout, 4, 4) -> [4 classes][rows][K_pad]; class (py,px), tap (ty,tx):
+// ky = 3 - py - 2*ty, kx = 3 - px - 2*tx ; k = (ty*2 + tx)*cin_pad + ci
+static void pack_deconv2x_w(const HostParam& w, int cin_pad, int rows, int K_pad, std::vector<float>& out)
+{
+    const int Cin = (int)w.shape[0], Cout = (int)w.shape[1];
+    out.assign((size_t)4 * rows * K_pad, 0.f);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            float* base = out.data() + (size_t)(py * 2 + px) * rows * K_pad;
+            for (int co = 0; co < Cout; ++co)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        const int ky = 3 - py - 2 * ty, kx = 3 - px - 2 * tx;
+                        for (int ci = 0; ci < Cin; ++ci)
+                            base[(size_t)co * K_pad + (size_t)(ty * 2 + tx) * cin_pad + ci] =
+                                w.data[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                    }
+        }
+}
+
+static int finalize_conv(accel_plan* p, Op& op)
+{
+    accel_model* m = p->m;
+    const KV& kv = op.kv;
+    int rc;
+    if ((rc = parse_buf(kv, "in", op.a)) || (rc = parse_buf(kv, "out", op.b)) ||
+        (rc = parse_buf(kv, "out2", op.c)) || (rc = parse_buf(kv, "res", op.d))) return rc;
+    if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "out"))) return rc;
+    if (op.c.set && (rc = resolve(p, op.c, "out2"))) return rc;
+    if (op.d.set && (rc = resolve(p, op.d, "res"))) return rc;
+
+    const std::string wname = kv_str(kv, "w");
+    const HostParam* w = get_param(m, wname);
+    if (!w) return fail(ACCEL_ERR_PARAM, "%s not initialized", wname.c_str());
+    if (w->shape.size() != 4) return fail(ACCEL_ERR_PARAM, "%s: expected a 4-d weight", wname.c_str());
+    const std::string mode = kv_str(kv, "mode", "conv");
+    const bool deconv = mode == "deconv2x";
+    const bool cols = mode == "cols";
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    kv_pair(kv, "k", kh, kw, 1, 1);
+    kv_pair(kv, "s", sh, sw, 1, 1);
+    kv_pair(kv, "p", ph, pw, 0, 0);
+    kv_pair(kv, "d", dh, dw, 1, 1);
+    const int cin = (int)kv_int(kv, "cin"), cout = (int)kv_int(kv, "cout");
+    const int cin_pad = roundup(cin, 4);
+    const int cout_store = roundup(cout, 4);
+    const int rows = roundup(cout_store, 128);
+    if (cout_store > op.b.Cs) return fail(ACCEL_ERR_PLAN, "conv %s: output view too narrow (%d > Cs %d)", op.name.c_str(), cout_store, op.b.Cs);
+
+    ConvParams& c = op.conv;
+    memset(&c, 0, sizeof c);
+    std::vector<float> packed;
+    if (deconv) {
+        if (w->shape[0] != cin || w->shape[1] != cout || w->shape[2] != 4 || w->shape[3] != 4)
+            return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,4,4)", wname.c_str(), cin, cout);
+        c.kh = c.kw = 2; c.sh = c.sw = 1; c.dh = c.dw = 1; c.ph = c.pw = 0;
+        c.Cin = cin_pad;
+        c.K_pad = roundup(4 * cin_pad, 32);
+        pack_deconv2x_w(*w, cin_pad, rows, c.K_pad, packed);
+        c.deconv2x = 1;
+        c.w_class_stride = (size_t)rows * c.K_pad;
+        c.Ho = op.a.H; c.Wo = op.a.W;
+        c.yH = op.b.H; c.yW = op.b.W;
+        if (op.b.H != 2 * op.a.H || op.b.W != 2 * op.a.W)
+            return fail(ACCEL_ERR_PLAN, "deconv2x %s: output must be exactly 2x the input", op.name.c_str());
+    } else {
+        int wkh = kh, wkw = kw;
+        if (cols) kv_pair(kv, "wk", wkh, wkw, 3, 3);
+        if (w->shape[0] != cout || w->shape[1] != cin || w->shape[2] != wkh || w->shape[3] != wkw)
+            return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,%d,%d) got (%ld,%ld,%ld,%ld)",
+                        wname.c_str(), cout, cin, wkh, wkw, (long)w->shape[0], (long)w->shape[1], (long)w->shape[2], (long)w->shape[3]);
+        const int Kreal = wkh * wkw * cin_pad;
+        c.K_pad = roundup(Kreal, 32);
+        pack_conv_w(*w, cin_pad, rows, c.K_pad, packed);
+        if (cols) { c.kh = c.kw = 1; c.Cin = Kreal; }
+        else { c.kh = kh; c.kw = kw; c.Cin = cin_pad; }
+        c.sh = sh; c.sw = sw; c.ph = ph; c.pw = pw; c.dh = dh; c.dw = dw;
+        c.Ho = op.b.H; c.Wo = op.b.W;
+        c.yH = op.b.H; c.yW = op.b.W;
+        const int eh = (op.a.H + 2 * c.ph - c.dh * (c.kh - 1) - 1) / c.sh + 1;
+        const int ew = (op.a.W + 2 * c.pw - c.dw * (c.kw - 1) - 1) / c.sw + 1;
+        if (eh != op.b.H || ew != op.b.W)
+            return fail(ACCEL_ERR_PLAN, "conv %s: output %dx%d does not match geometry %dx%d", op.name.c_str(), op.b.H, op.b.W, eh, ew);
+        if (c.Cin > op.a.Cs) return fail(ACCEL_ERR_PLAN, "conv %s: input view narrower than Cin", op.name.c_str());
+    }
+    void* dw_ = nullptr;
+    if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
+    c.w = static_cast<const float*>(dw_);
+
+    // epilogue scale / shift
+    std::vector<float> scale(rows, 0.f), shift(rows, 0.f);
+    for (int i = 0; i < cout; ++i) scale[i] = 1.f;
+    if (kv_has(kv, "bn")) {
+        std::vector<float> s, b;
+        if ((rc = bn_fold(m, kv_str(kv, "bn"), (float)kv_f(kv, "eps", 1e-5), (int)kv_int(kv, "fixg", 0), cout, s, b))) return rc;
+        for (int i = 0; i < cout; ++i) { scale[i] = s[i]; shift[i] = b[i]; }
+    }
+    if (kv_has(kv, "bias")) {
+        const HostParam* bias = get_param(m, kv_str(kv, "bias"));
+        if (!bias) return fail(ACCEL_ERR_PARAM, "%s not initialized", kv_str(kv, "bias").c_str());
+        if ((int)bias->numel() != cout) return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s", kv_str(kv, "bias").c_str());
+        for (int i = 0; i < cout; ++i) shift[i] += bias->data[i] * scale[i];
+    }
+    if (kv_has(kv, "mul")) {
+        const float mul = (float)kv_f(kv, "mul", 1.0);
+        for (int i = 0; i < cout; ++i) { scale[i] *= mul; shift[i] *= mul; }
+    }
+    void *ds = nullptr, *db = nullptr;
+    if ((rc = dev_upload(p, scale.data(), rows * sizeof(float), &ds)) ||
+        (rc = dev_upload(p, shift.data(), rows * sizeof(float), &db))) return rc;
+    c.scale = static_cast<const float*>(ds);
+    c.shift = static_cast<const float*>(db);
+    if (op.c.set) {
+        std::vector<float> s2(rows, 0.f), b2(rows, 0.f), s, b;
+        if (!kv_has(kv, "bn2")) return fail(ACCEL_ERR_PLAN, "conv %s: out2 needs bn2", op.name.c_str());
+        if ((rc = bn_fold(m, kv_str(kv, "bn2"), (float)kv_f(kv, "eps2", 2e-5), (int)kv_int(kv, "fixg2", 0), cout, s, b))) return rc;
+        for (int i = 0; i < cout; ++i) { s2[i] = s[i]; b2[i] = b[i]; }
+        void *d2 = nullptr, *e2 = nullptr;
+        if ((rc = dev_upload(p, s2.data(), rows * sizeof(float), &d2)) ||
+            (rc = dev_upload(p, b2.data(), rows * sizeof(float), &e2))) return rc;
+        c.scale2 = static_cast<const float*>(d2);
+        c.shift2 = static_cast<const float*>(e2);
+        c.y2 = op.c.ptr; c.y2Cs = op.c.Cs;
+    }
+    c.x = op.a.ptr; c.xCs = op.a.Cs; c.H = op.a.H; c.W = op.a.W;
+    c.y = op.b.ptr; c.yCs = op.b.Cs;
+    if (op.d.set) { c.res = op.d.ptr; c.resCs = op.d.Cs; }
+    c.Cout_store = cout_store;
+    c.M = c.Ho * c.Wo;
+    c.act = (int)kv_int(kv, "act", 0);
+    c.slope = (float)kv_f(kv, "slope", 0.1);
+    c.force_tile = (int)kv_int(kv, "tile", -1);
+    return 0;
+}
+
+static int upload_param(accel_plan* p, const std::string& name, size_t expect, const float** out)
+{
+    const HostParam* h = get_param(p->m, name);
+    if (!h) return fail(ACCEL_ERR_PARAM, "%s not initialized", name.c_str());
+    if (expect && h->numel() != expect) return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: %zu elements, expected %zu", name.c_str(), h->numel(), expect);
+    void* d = nullptr;
+    int rc = dev_upload(p, h->data.data(), h->numel() * sizeof(float), &d);
+    if (rc) return rc;
+    *out = static_cast<const float*>(d);
+    return 0;
+}
+
+static int finalize_op(accel_plan* p, Op& op)
+{
+    const KV& kv = op.kv;
+    int rc;
+    switch (op.kind) {
+    case OP_CONV:
+        return finalize_conv(p, op);
+    case OP_PREP_RGB: {
+        if ((rc = parse_buf(kv, "src", op.a)) || (rc = parse_buf(kv, "dst", op.b))) return rc;
+        if ((rc = resolve(p, op.a, "src")) || (rc = resolve(p, op.b, "dst"))) return rc;
+        op.H = (int)kv_int(kv, "H"); op.W = (int)kv_int(kv, "W");
+        if (op.b.Cs != 4) return fail(ACCEL_ERR_PLAN, "prep_rgb: dst must be NHWC4");
+        if (kv_has(kv, "bn")) {
+            std::vector<float> s, b;
+            if ((rc = bn_fold(p->m, kv_str(kv, "bn"), (float)kv_f(kv, "eps", 2e-5), (int)kv_int(kv, "fixg", 1), 3, s, b))) return rc;
+            void *ds = nullptr, *db = nullptr;
+            if ((rc = dev_upload(p, s.data(), 12, &ds)) || (rc = dev_upload(p, b.data(), 12, &db))) return rc;
+            op.p0 = static_cast<const float*>(ds); op.p1 = static_cast<const float*>(db);
+        }
+        return 0;
+    }
+    case OP_PREP_FLOW: {
+        if ((rc = parse_buf(kv, "cur", op.a)) || (rc = parse_buf(kv, "prev", op.b)) || (rc = parse_buf(kv, "dst", op.c))) return rc;
+        if ((rc = resolve(p, op.a, "cur")) || (rc = resolve(p, op.b, "prev")) || (rc = resolve(p, op.c, "dst"))) return rc;
+        op.H = (int)kv_int(kv, "H"); op.W = (int)kv_int(kv, "W");
+        if (op.c.Cs != 8 || (op.H & 1) || (op.W & 1)) return fail(ACCEL_ERR_PLAN, "prep_flow: dst must be NHWC8 and H,W even");
+        return 0;
+    }
+    case OP_POOL: {
+        if ((rc = parse_buf(kv, "in", op.a)) || (rc = parse_buf(kv, "out", op.b))) return rc;
+        if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "out"))) return rc;
+        PoolParams& q = op.pool;
+        memset(&q, 0, sizeof q);
+        q.x = op.a.ptr; q.y = op.b.ptr; q.xCs = op.a.Cs; q.yCs = op.b.Cs;
+        q.C4 = roundup(op.a.C, 4) / 4;
+        q.H = op.a.H; q.W = op.a.W; q.Ho = op.b.H; q.Wo = op.b.W;
+        kv_pair(kv, "k", q.kh, q.kw, 2, 2);
+        kv_pair(kv, "s", q.sh, q.sw, 2, 2);
+        kv_pair(kv, "p", q.ph, q.pw, 0, 0);
+        q.is_max = kv_str(kv, "kind", "max") == "max";
+        q.relu = (int)kv_int(kv, "act", 0) == 1;
+        if (kv_has(kv, "bn")) {
+            std::vector<float> s, b;
+            if ((rc = bn_fold(p->m, kv_str(kv, "bn"), (float)kv_f(kv, "eps", 2e-5), (int)kv_int(kv, "fixg", 0), op.a.C, s, b))) return rc;
+            s.resize(q.C4 * 4, 0.f); b.resize(q.C4 * 4, 0.f);
+            void *ds = nullptr, *db = nullptr;
+            if ((rc = dev_upload(p, s.data(), s.size() * 4, &ds)) || (rc = dev_upload(p, b.data(), b.size() * 4, &db))) return rc;
+            q.scale = static_cast<const float*>(ds); q.shift = static_cast<const float*>(db);
+        }
+        return 0;
+    }
+    case OP_WARP: {
+        if ((rc = parse_buf(kv, "feat", op.a)) || (rc = parse_buf(kv, "flow", op.b)) || (rc = parse_buf(kv, "out", op.c))) return rc;
+        if ((rc = resolve(p, op.a, "feat")) || (rc = resolve(p, op.b, "flow")) || (rc = resolve(p, op.c, "out"))) return rc;
+        if (op.a.C % 4) return fail(ACCEL_ERR_PLAN, "warp: C must be a multiple of 4");
+        return 0;
+    }
+    case OP_DCN_COLS: {
+        if ((rc = parse_buf(kv, "in", op.a)) || (rc = parse_buf(kv, "off", op.b)) || (rc = parse_buf(kv, "out", op.c))) return rc;
+        if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "off")) || (rc = resolve(p, op.c, "out"))) return rc;
+        DcnColsParams& q = op.dcn;
+        memset(&q, 0, sizeof q);
+        q.x = op.a.ptr; q.off = op.b.ptr; q.col = op.c.ptr;
+        q.C = roundup(op.a.C, 4); q.xCs = op.a.Cs; q.offCs = op.b.Cs; q.colCs = op.c.Cs;
+        q.H = op.a.H; q.W = op.a.W; q.Ho = op.c.H; q.Wo = op.c.W;
+        kv_pair(kv, "k", q.kh, q.kw, 3, 3);
+        kv_pair(kv, "s", q.sh, q.sw, 1, 1);
+        kv_pair(kv, "p", q.ph, q.pw, 0, 0);
+        kv_pair(kv, "d", q.dh, q.dw, 1, 1);
+        q.dg = (int)kv_int(kv, "dg", 1);
+        if (op.a.C % q.dg || (op.a.C / q.dg) % 4) return fail(ACCEL_ERR_PLAN, "dcn_cols: channels per deformable group must be a multiple of 4");
+        if (q.colCs < q.kh * q.kw * q.C) return fail(ACCEL_ERR_PLAN, "dcn_cols: column buffer too narrow");
+        return 0;
+    }
+    case OP_SCORE_TAIL: {
+        if ((rc = parse_buf(kv, "left", op.a)) || (rc = parse_buf(kv, "right", op.b)) ||
+            (rc = parse_buf(kv, "logits", op.c)) || (rc = parse_buf(kv, "labels", op.d))) return rc;
+        if ((rc = resolve(p, op.a, "left")) || (rc = resolve(p, op.c, "logits")) || (rc = resolve(p, op.d, "labels"))) return rc;
+        if (op.b.set && (rc = resolve(p, op.b, "right"))) return rc;
+        ScoreTailParams& q = op.tail;
+        memset(&q, 0, sizeof q);
+        q.ncls = (int)kv_int(kv, "ncls", 19);
+        q.left = op.a.ptr; q.lCs = op.a.Cs; q.Hs = op.a.H; q.Ws = op.a.W;
+        q.H = (int)kv_int(kv, "H"); q.W = (int)kv_int(kv, "W");
+        if (q.H != 16 * q.Hs || q.W != 16 * q.Ws) return fail(ACCEL_ERR_PLAN, "score_tail: output must be 16x the score map");
+        q.logits = op.c.ptr; q.labels = reinterpret_cast<unsigned char*>(op.d.ptr);
+        const size_t wn = (size_t)q.ncls * 32 * 32;
+        if ((rc = upload_param(p, kv_str(kv, "wl"), wn, &q.wl))) return rc;
+        if (op.b.set) {
+            q.right = op.b.ptr; q.rCs = op.b.Cs;
+            if ((rc = upload_param(p, kv_str(kv, "wr"), wn, &q.wr)) ||
+                (rc = upload_param(p, kv_str(kv, "cw"), (size_t)q.ncls * 2 * q.ncls, &q.cw)) ||
+                (rc = upload_param(p, kv_str(kv, "cb"), (size_t)q.ncls, &q.cb))) return rc;
+        }
+        return 0;
+    }
+    case OP_COPY: {
+        if ((rc = parse_buf(kv, "src", op.a)) || (rc = parse_buf(kv, "dst", op.b))) return rc;
+        if ((rc = resolve(p, op.a, "src")) || (rc = resolve(p, op.b, "dst"))) return rc;
+        if (op.a.H != op.b.H || op.a.W != op.b.W || op.a.C != op.b.C) return fail(ACCEL_ERR_PLAN, "copy: view shapes differ");
+        return 0;
+    }
+    case OP_EXPORT_NCHW:
+    case OP_IMPORT_NCHW: {
+        if ((rc = parse_buf(kv, "src", op.a)) || (rc = parse_buf(kv, "dst", op.b))) return rc;
+        if ((rc = resolve(p, op.a, "src")) || (rc = resolve(p, op.b, "dst"))) return rc;
+        return 0;
+    }
+    }
+    return fail(ACCEL_ERR_PLAN, "unhandled op kind");
+}
+
+static int launch_op(accel_plan* p, Op& op)
+{
+    hipStream_t st = p->m->ctx->stream;
+    hipError_t e = hipSuccess;
+    switch (op.kind) {
+    case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
+    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, st); break;
+    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, st); break;
+    case OP_POOL: e = launch_pool(op.pool, st); break;
+    case OP_WARP: e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W, st); break;
+    case OP_DCN_COLS: e = launch_dcn_cols(op.dcn, st); break;
+    case OP_SCORE_TAIL: e = launch_score_tail(op.tail, st); break;
+    case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.H * op.a.W, st); break;
+    case OP_EXPORT_NCHW: e = launch_nhwc_to_nchw(op.a.ptr, op.a.Cs, op.b.ptr, op.a.C, op.a.H, op.a.W, st); break;
+    case OP_IMPORT_NCHW: e = launch_nchw_to_nhwc(op.a.ptr, op.b.ptr, op.b.Cs, op.b.C, op.b.H, op.b.W, st); break;
+    }
+    if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "launch of op %s (%s) failed: %s", op.kind_name.c_str(), op.name.c_str(), hipGetErrorString(e));
+    return 0;
+}
+
+static int run_eager(accel_plan* p)
+{
+    for (Op& op : p->ops) {
+        int rc = launch_op(p, op);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
+{
+    if (!out) return fail(ACCEL_ERR_ARG, "accel_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(ACCEL_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(ACCEL_ERR_ARG, "device %d out of range (%d devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    accel_ctx* c = new accel_ctx();
+    c->device = device_id;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(ACCEL_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
+    *out = c;
+    return 0;
+}
+
+extern "C" int accel_ctx_destroy(accel_ctx* ctx)
+{
+    if (!ctx) return 0;
+    hipStreamSynchronize(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int accel_sync(accel_ctx* ctx)
+{
+    if (!ctx) return fail(ACCEL_ERR_ARG, "accel_sync: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" void* accel_ctx_stream(accel_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int accel_model_create(accel_ctx* ctx, accel_model** out)
+{
+    if (!ctx || !out) return fail(ACCEL_ERR_ARG, "accel_model_create: NULL argument");
+    accel_model* m = new accel_model();
+    m->ctx = ctx;
+    *out = m;
+    return 0;
+}
+
+static void plan_free(accel_plan* p)
+{
+    if (p->gexec) hipGraphExecDestroy(p->gexec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    for (void* d : p->owned) hipFree(d);
+    if (p->arena) hipFree(p->arena);
+    delete p;
+}
+
+extern "C" int accel_model_destroy(accel_model* m)
+{
+    if (!m) return 0;
+    hipStreamSynchronize(m->ctx->stream);
+    for (accel_plan* p : m->plans) plan_free(p);
+    for (auto& kv : m->pbufs) hipFree(kv.second.ptr);
+    delete m;
+    return 0;
+}
+
+extern "C" int accel_model_set_param(accel_model* m, const char* name, const float* data, int ndim, const int64_t* shape)
+{
+    if (!m || !name || !data || ndim < 0 || ndim > 8 || (ndim && !shape)) return fail(ACCEL_ERR_ARG, "accel_model_set_param: bad argument");
+    HostParam hp;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { hp.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    hp.data.assign(data, data + n);
+    m->params[name] = std::move(hp);
+    return 0;
+}
+
+extern "C" int accel_model_has_param(accel_model* m, const char* name)
+{
+    return m && name && m->params.count(name) ? 1 : 0;
+}
+
+extern "C" int accel_model_add_plan(accel_model* m, const char* role, const char* plan_text, accel_plan** out)
+{
+    if (!m || !plan_text || !out) return fail(ACCEL_ERR_ARG, "accel_model_add_plan: NULL argument");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    accel_plan* p = new accel_plan();
+    p->m = m;
+    p->role = role ? role : "";
+    int rc = parse_plan(p, plan_text);
+    if (rc) { delete p; return rc; }
+    m->plans.push_back(p);
+    if (role && *role) m->roles[role] = p;
+    *out = p;
+    return 0;
+}
+
+extern "C" int accel_plan_finalize(accel_plan* p)
+{
+    if (!p) return fail(ACCEL_ERR_ARG, "accel_plan_finalize: NULL plan");
+    if (p->finalized) return 0;
+    HIP_TRY(hipSetDevice(p->m->ctx->device));
+    if (p->arena_bytes) {
+        HIP_TRY(hipMalloc((void**)&p->arena, p->arena_bytes));
+        HIP_TRY(hipMemsetAsync(p->arena, 0, p->arena_bytes, p->m->ctx->stream));
+    }
+    for (Op& op : p->ops) {
+        int rc = finalize_op(p, op);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    const char* g = getenv("ACCEL_HIP_GRAPH");
+    const bool use_graph = p->allow_graph && !(g && g[0] == '0');
+    if (use_graph) {
+        hipStream_t st = p->m->ctx->stream;
+        // one eager warm-up run: lazy module loading / function attributes must not happen under capture
+        int rc = run_eager(p);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = run_eager(p);
+        hipError_t e = hipStreamEndCapture(st, &p->graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
+    }
+    p->finalized = true;
+    return 0;
+}
+
+extern "C" int accel_plan_run(accel_plan* p)
+{
+    if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run: plan not finalized");
+    if (p->gexec) {
+        HIP_TRY(hipGraphLaunch(p->gexec, p->m->ctx->stream));
+        return 0;
+    }
+    return run_eager(p);
+}
+
+extern "C" int accel_plan_num_ops(accel_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double* flops, double* bytes)
+{
+    if (!p || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_info: index out of range");
+    const Op& op = p->ops[i];
+    if (kind32) { strncpy(kind32, op.kind_name.c_str(), 31); kind32[31] = 0; }
+    if (name64) { strncpy(name64, op.name.c_str(), 63); name64[63] = 0; }
+    if (flops) *flops = op.flops;
+    if (bytes) *bytes = op.bytes;
+    return 0;
+}
+
+extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
+{
+    if (!p || !p->finalized || !ms || n_ms < (int)p->ops.size() || iters < 1) return fail(ACCEL_ERR_ARG, "accel_plan_profile: bad argument");
+    hipStream_t st = p->m->ctx->stream;
+    const size_t n = p->ops.size();
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    int rc = 0;
+    for (int it = 0; it < iters && !rc; ++it) {
+        for (size_t i = 0; i < n && !rc; ++i) {
+            HIP_TRY(hipEventRecord(ev[2 * i], st));
+            rc = launch_op(p, p->ops[i]);
+            HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n && !rc; ++i) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += t;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
+    return rc;
+}
+
+extern "C" int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device)
+{
+    if (!m || !buf || !src) return fail(ACCEL_ERR_ARG, "accel_model_write: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_write: unknown buffer '%s'", buf);
+    if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_write: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
+    HIP_TRY(hipMemcpyAsync(it->second.ptr, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
+    if (!src_on_device) HIP_TRY(hipStreamSynchronize(m->ctx->stream));   // pageable source may be reused by the caller
+    return 0;
+}
+
+extern "C" int accel_model_read(accel_model* m, const char* buf, void* dst, size_t bytes, int dst_on_device)
+{
+    if (!m || !buf || !dst) return fail(ACCEL_ERR_ARG, "accel_model_read: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_read: unknown buffer '%s'", buf);
+    if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_read: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
+    HIP_TRY(hipMemcpyAsync(dst, it->second.ptr, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+    if (!dst_on_device) HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+extern "C" int accel_model_buffer(accel_model* m, const char* buf, void** dev_ptr, size_t* bytes)
+{
+    if (!m || !buf) return fail(ACCEL_ERR_ARG, "accel_model_buffer: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_buffer: unknown buffer '%s'", buf);
+    if (dev_ptr) *dev_ptr = it->second.ptr;
+    if (bytes) *bytes = it->second.bytes;
+    return 0;
+}
+
+static size_t pbuf_bytes(accel_model* m, const char* name)
+{
+    auto it = m->pbufs.find(name);
+    return it == m->pbufs.end() ? 0 : it->second.bytes;
+}
+
+static int frame_outputs(accel_model* m, float* feat_out, float* logits_out, uint8_t* labels_out, int on_dev)
+{
+    int rc;
+    if (feat_out) {
+        // `feat` lives NHWC in HBM; the plan's optional export op fills `feat_nchw` only when present
+        auto it = m->pbufs.find("feat_nchw");
+        if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "feat_out requested but the plans carry no feat_nchw export");
+        if ((rc = accel_model_read(m, "feat_nchw", feat_out, it->second.bytes, on_dev))) return rc;
+    }
+    if (logits_out && (rc = accel_model_read(m, "logits", logits_out, pbuf_bytes(m, "logits"), on_dev))) return rc;
+    if (labels_out && (rc = accel_model_read(m, "labels", labels_out, pbuf_bytes(m, "labels"), on_dev))) return rc;
+    return 0;
+}
+
+extern "C" int accel_key_forward(accel_model* m, const float* img, int img_on_device,
+                                 float* feat_out, float* logits_out, uint8_t* labels_out, int out_on_device)
+{
+    if (!m) return fail(ACCEL_ERR_ARG, "accel_key_forward: NULL model");
+    auto it = m->roles.find("key");
+    if (it == m->roles.end()) return fail(ACCEL_ERR_ARG, "accel_key_forward: model has no 'key' plan");
+    int rc;
+    if (img && (rc = accel_model_write(m, "data", img, pbuf_bytes(m, "data"), img_on_device))) return rc;
+    if ((rc = accel_plan_run(it->second))) return rc;
+    return frame_outputs(m, feat_out, logits_out, labels_out, out_on_device);
+}
+
+extern "C" int accel_cur_forward(accel_model* m, const float* img_cur, const float* img_prev, int img_on_device,
+                                 float* feat_out, float* logits_out, uint8_t* labels_out, int out_on_device)
+{
+    if (!m) return fail(ACCEL_ERR_ARG, "accel_cur_forward: NULL model");
+    auto it = m->roles.find("cur");
+    if (it == m->roles.end()) return fail(ACCEL_ERR_ARG, "accel_cur_forward: model has no 'cur' plan");
+    int rc;
+    if (img_cur && (rc = accel_model_write(m, "data", img_cur, pbuf_bytes(m, "data"), img_on_device))) return rc;
+    if (img_prev && (rc = accel_model_write(m, "data_key", img_prev, pbuf_bytes(m, "data_key"), img_on_device))) return rc;
+    if ((rc = accel_plan_run(it->second))) return rc;
+    return frame_outputs(m, feat_out, logits_out, labels_out, out_on_device);
+}
+
+// ---------------------------------------------------------------------------
+// operator-level entry points: one-op plans over temporary models
+// ---------------------------------------------------------------------------
+namespace {
+struct TempModel {
+    accel_model* m = nullptr;
+    ~TempModel() { if (m) accel_model_destroy(m); }
+};
+
+std::string bref(const char* space, size_t off, int C, int Cs, int H, int W)
+{
+    char b[160];
+    snprintf(b, sizeof b, "%s:%zu:%d:%d:%d:%d", space, off, C, Cs, H, W);
+    return b;
+}
+
+int set1(accel_model* m, const char* name, const float* d, std::initializer_list<int64_t> shp)
+{
+    std::vector<int64_t> s(shp);
+    return accel_model_set_param(m, name, d, (int)s.size(), s.data());
+}
+
+int run_text(accel_model* m, const std::string& text)
+{
+    accel_plan* p = nullptr;
+    int rc = accel_model_add_plan(m, "op", text.c_str(), &p);
+    if (rc) return rc;
+    if ((rc = accel_plan_finalize(p))) return rc;
+    if ((rc = accel_plan_run(p))) return rc;
+    return accel_sync(m->ctx);
+}
+}  // namespace
+
+static size_t al(size_t b) { return (b + 255) / 256 * 256; }
+
+extern "C" int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                            const float* w, const float* bias, int K, int kh, int kw,
+                            int sh, int sw, int ph, int pw, int dh, int dw,
+                            const float* scale, const float* shift, const float* residual,
+                            int act, float slope, int force_tile, float* y)
+{
+    if (!ctx || !x || !w || !y) return fail(ACCEL_ERR_ARG, "accel_conv2d: NULL argument");
+    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_conv2d: N must be 1 (TEST.BATCH_IMAGES = 1 on this path)");
+    const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+    if (Ho <= 0 || Wo <= 0) return fail(ACCEL_ERR_ARG, "accel_conv2d: empty output");
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    if ((rc = set1(t.m, "w_weight", w, {K, C, kh, kw}))) return rc;
+    if (bias && (rc = set1(t.m, "w_bias", bias, {K}))) return rc;
+    if (scale) {   // expressed as a BatchNorm with gamma=scale, beta=shift, mean=0, var=1-eps
+        std::vector<float> zero(K, 0.f), var(K, 1.0f);
+        if ((rc = set1(t.m, "e_gamma", scale, {K})) || (rc = set1(t.m, "e_beta", shift, {K})) ||
+            (rc = set1(t.m, "e_moving_mean", zero.data(), {K})) || (rc = set1(t.m, "e_moving_var", var.data(), {K}))) return rc;
+    }
+    const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4;
+    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)K * Ho * Wo * 4;
+    size_t off = 0;
+    const size_t o_x = off; off += al((size_t)H * W * Cp * 4);
+    const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
+    const size_t o_r = off; if (residual) off += al((size_t)Ho * Wo * Kp * 4);
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << off << "\n";
+    s << "pbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
+    if (residual) s << "pbuf name=r bytes=" << yout << "\n";
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
+    if (residual) s << "import_nchw src=" << bref("r", 0, K, K, Ho, Wo) << " dst=" << bref("A", o_r, K, Kp, Ho, Wo) << "\n";
+    s << "conv name=op in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, K, Kp, Ho, Wo)
+      << " w=w_weight" << (bias ? " bias=w_bias" : "") << (scale ? " bn=e eps=0 fixg=0" : "")
+      << " act=" << act << " slope=" << slope << " k=" << kh << "," << kw << " s=" << sh << "," << sw
+      << " p=" << ph << "," << pw << " d=" << dh << "," << dw << " cin=" << C << " cout=" << K
+      << " tile=" << force_tile;
+    if (residual) s << " res=" << bref("A", o_r, K, Kp, Ho, Wo);
+    s << "\nexport_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;
+    if (residual && (rc = accel_model_write(t.m, "r", residual, yout, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", y, yout, 0);
+}
+
+extern "C" int accel_deconv2d_4x4s2(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                                    const float* w, const float* bias, int K, int act, float slope, float* y)
+{
+    if (!ctx || !x || !w || !y) return fail(ACCEL_ERR_ARG, "accel_deconv2d_4x4s2: NULL argument");
+    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_deconv2d_4x4s2: N must be 1");
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    if ((rc = set1(t.m, "w_weight", w, {C, K, 4, 4}))) return rc;
+    if (bias && (rc = set1(t.m, "w_bias", bias, {K}))) return rc;
+    const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4, Ho = 2 * H, Wo = 2 * W;
+    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)K * Ho * Wo * 4;
+    const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Kp * 4);
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
+    s << "conv name=op mode=deconv2x in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, K, Kp, Ho, Wo)
+      << " w=w_weight" << (bias ? " bias=w_bias" : "") << " act=" << act << " slope=" << slope
+      << " cin=" << C << " cout=" << K << "\n";
+    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", y, yout, 0);
+}
+
+extern "C" int accel_deform_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                                   const float* offset, const float* w, int K, int kh, int kw,
+                                   int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* y)
+{
+    if (!ctx || !x || !offset || !w || !y) return fail(ACCEL_ERR_ARG, "accel_deform_conv2d: NULL argument");
+    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_deform_conv2d: N must be 1");
+    const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    if ((rc = set1(t.m, "w_weight", w, {K, C, kh, kw}))) return rc;
+    const int OC = 2 * kh * kw * dg;
+    const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4, OCp = (OC + 3) / 4 * 4, CC = kh * kw * Cp;
+    const size_t xin = (size_t)C * H * W * 4, oin = (size_t)OC * Ho * Wo * 4, yout = (size_t)K * Ho * Wo * 4;
+    size_t off = 0;
+    const size_t o_x = off; off += al((size_t)H * W * Cp * 4);
+    const size_t o_o = off; off += al((size_t)Ho * Wo * OCp * 4);
+    const size_t o_c = off; off += al((size_t)Ho * Wo * CC * 4);
+    const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << off << "\npbuf name=x bytes=" << xin << "\npbuf name=o bytes=" << oin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
+    s << "import_nchw src=" << bref("o", 0, OC, OC, Ho, Wo) << " dst=" << bref("A", o_o, OC, OCp, Ho, Wo) << "\n";
+    s << "dcn_cols in=" << bref("A", o_x, C, Cp, H, W) << " off=" << bref("A", o_o, OC, OCp, Ho, Wo)
+      << " out=" << bref("A", o_c, CC, CC, Ho, Wo) << " k=" << kh << "," << kw << " s=" << sh << "," << sw
+      << " p=" << ph << "," << pw << " d=" << dh << "," << dw << " dg=" << dg << "\n";
+    s << "conv name=op mode=cols wk=" << kh << "," << kw << " in=" << bref("A", o_c, CC, CC, Ho, Wo)
+      << " out=" << bref("A", o_y, K, Kp, Ho, Wo) << " w=w_weight act=0 k=1,1 cin=" << C << " cout=" << K << "\n";
+    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "x", x, xin, 0)) || (rc = accel_model_write(t.m, "o", offset, oin, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", y, yout, 0);
+}
+
+extern "C" int accel_pool2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W, int is_max, int full,
+                            int kh, int kw, int sh, int sw, int ph, int pw,
+                            const float* scale, const float* shift, int relu, float* y)
+{
+    if (!ctx || !x || !y) return fail(ACCEL_ERR_ARG, "accel_pool2d: NULL argument");
+    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_pool2d: N must be 1");
+    auto po = [&](int in, int k, int s, int p) {
+        return full ? 1 + (in + 2 * p - k + s - 1) / s : 1 + (in + 2 * p - k) / s;
+    };
+    const int Ho = po(H, kh, sh, ph), Wo = po(W, kw, sw, pw);
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    if (scale) {
+        std::vector<float> zero(C, 0.f), var(C, 1.0f);
+        if ((rc = set1(t.m, "e_gamma", scale, {C})) || (rc = set1(t.m, "e_beta", shift, {C})) ||
+            (rc = set1(t.m, "e_moving_mean", zero.data(), {C})) || (rc = set1(t.m, "e_moving_var", var.data(), {C}))) return rc;
+    }
+    const int Cp = (C + 3) / 4 * 4;
+    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)C * Ho * Wo * 4;
+    const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Cp * 4);
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
+    s << "pool in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, C, Cp, Ho, Wo)
+      << " kind=" << (is_max ? "max" : "avg") << " k=" << kh << "," << kw << " s=" << sh << "," << sw
+      << " p=" << ph << "," << pw << (scale ? " bn=e eps=0 fixg=0" : "") << " act=" << (relu ? 1 : 0) << "\n";
+    s << "export_nchw src=" << bref("A", o_y, C, Cp, Ho, Wo) << " dst=" << bref("y", 0, C, C, Ho, Wo) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", y, yout, 0);
+}
+
+extern "C" int accel_flow_warp(accel_ctx* ctx, const float* feat, int C, int H, int W, const float* flow, float* out)
+{
+    if (!ctx || !feat || !flow || !out) return fail(ACCEL_ERR_ARG, "accel_flow_warp: NULL argument");
+    if (C % 4) return fail(ACCEL_ERR_ARG, "accel_flow_warp: C must be a multiple of 4");
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    const size_t fb = (size_t)C * H * W * 4, flb = (size_t)2 * H * W * 4;
+    const size_t o_f = 0, o_fl = al(fb), o_o = o_fl + al((size_t)H * W * 16), tot = o_o + al(fb);
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << tot << "\npbuf name=f bytes=" << fb << "\npbuf name=fl bytes=" << flb << "\npbuf name=y bytes=" << fb << "\n";
+    s << "import_nchw src=" << bref("f", 0, C, C, H, W) << " dst=" << bref("A", o_f, C, C, H, W) << "\n";
+    s << "import_nchw src=" << bref("fl", 0, 2, 2, H, W) << " dst=" << bref("A", o_fl, 2, 4, H, W) << "\n";
+    s << "warp feat=" << bref("A", o_f, C, C, H, W) << " flow=" << bref("A", o_fl, 2, 4, H, W) << " out=" << bref("A", o_o, C, C, H, W) << "\n";
+    s << "export_nchw src=" << bref("A", o_o, C, C, H, W) << " dst=" << bref("y", 0, C, C, H, W) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "f", feat, fb, 0)) || (rc = accel_model_write(t.m, "fl", flow, flb, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", out, fb, 0);
+}
+
+extern "C" int accel_score_fuse(accel_ctx* ctx, const float* left, const float* right, int ncls, int Hs, int Ws,
+                                const float* wl, const float* wr, const float* cw, const float* cb,
+                                float* logits, uint8_t* labels)
+{
+    if (!ctx || !left || !wl || (!logits && !labels)) return fail(ACCEL_ERR_ARG, "accel_score_fuse: NULL argument");
+    if (right && (!wr || !cw || !cb)) return fail(ACCEL_ERR_ARG, "accel_score_fuse: right branch needs wr, cw, cb");
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    if ((rc = set1(t.m, "wl", wl, {ncls, 1, 32, 32}))) return rc;
+    if (right && ((rc = set1(t.m, "wr", wr, {ncls, 1, 32, 32})) || (rc = set1(t.m, "cw", cw, {ncls, 2 * ncls, 1, 1})) ||
+                  (rc = set1(t.m, "cb", cb, {ncls})))) return rc;
+    const int H = 16 * Hs, W = 16 * Ws, Cp = (ncls + 3) / 4 * 4;
+    const size_t sb = (size_t)ncls * Hs * Ws * 4, lb = (size_t)ncls * H * W * 4, yb = (size_t)H * W;
+    const size_t o_l = 0, o_r = al((size_t)Hs * Ws * Cp * 4), tot = 2 * o_r;
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << tot << "\npbuf name=l bytes=" << sb << "\npbuf name=r bytes=" << sb
+      << "\npbuf name=logits bytes=" << lb << "\npbuf name=labels bytes=" << al(yb) << "\n";
+    s << "import_nchw src=" << bref("l", 0, ncls, ncls, Hs, Ws) << " dst=" << bref("A", o_l, ncls, Cp, Hs, Ws) << "\n";
+    if (right) s << "import_nchw src=" << bref("r", 0, ncls, ncls, Hs, Ws) << " dst=" << bref("A", o_r, ncls, Cp, Hs, Ws) << "\n";
+    s << "score_tail left=" << bref("A", o_l, ncls, Cp, Hs, Ws) << " wl=wl";
+    if (right) s << " right=" << bref("A", o_r, ncls, Cp, Hs, Ws) << " wr=wr cw=cw cb=cb";
+    s << " logits=" << bref("logits", 0, ncls, 4, H, W) << " labels=" << bref("labels", 0, 1, 4, H, W)
+      << " H=" << H << " W=" << W << " ncls=" << ncls << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "l", left, sb, 0))) return rc;
+    if (right && (rc = accel_model_write(t.m, "r", right, sb, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    if (logits && (rc = accel_model_read(t.m, "logits", logits, lb, 0))) return rc;
+    if (labels && (rc = accel_model_read(t.m, "labels", labels, yb, 0))) return rc;
+    return 0;
+}
+
+extern "C" int accel_argmax_c(accel_ctx* ctx, const float* logits, int C, int H, int W, uint8_t* labels)
+{
+    if (!ctx || !logits || !labels) return fail(ACCEL_ERR_ARG, "accel_argmax_c: NULL argument");
+    float* d = nullptr;
+    unsigned char* l = nullptr;
+    const size_t lb = (size_t)C * H * W * 4;
+    HIP_TRY(hipMalloc((void**)&d, lb));
+    hipError_t e = hipMalloc((void**)&l, (size_t)H * W);
+    if (e != hipSuccess) { hipFree(d); return fail(ACCEL_ERR_HIP, "hipMalloc failed"); }
+    int rc = 0;
+    if (hipMemcpy(d, logits, lb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ACCEL_ERR_HIP, "H2D copy failed");
+    if (!rc && launch_argmax_nchw(d, l, C, H * W, ctx->stream) != hipSuccess) rc = fail(ACCEL_ERR_HIP, "argmax launch failed");
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ACCEL_ERR_HIP, "sync failed");
+    if (!rc && hipMemcpy(labels, l, (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ACCEL_ERR_HIP, "D2H copy failed");
+    hipFree(d); hipFree(l);
+    return rc;
+}
+
+extern "C" int accel_flow_input(accel_ctx* ctx, const float* cur, const float* prev, int H, int W, float* out)
+{
+    if (!ctx || !cur || !prev || !out) return fail(ACCEL_ERR_ARG, "accel_flow_input: NULL argument");
+    if ((H & 1) || (W & 1)) return fail(ACCEL_ERR_ARG, "accel_flow_input: H and W must be even");
+    TempModel t;
+    int rc;
+    if ((rc = accel_model_create(ctx, &t.m))) return rc;
+    const size_t ib = (size_t)3 * H * W * 4, ob = (size_t)6 * (H / 2) * (W / 2) * 4;
+    std::stringstream s;
+    s << "option graph=0\narena bytes=" << al((size_t)(H / 2) * (W / 2) * 32) << "\npbuf name=data bytes=" << ib << "\npbuf name=data_key bytes=" << ib
+      << "\npbuf name=y bytes=" << ob << "\n";
+    s << "prep_flow cur=" << bref("data", 0, 3, 4, H, W) << " prev=" << bref("data_key", 0, 3, 4, H, W)
+      << " dst=" << bref("A", 0, 6, 8, H / 2, W / 2) << " H=" << H << " W=" << W << "\n";
+    s << "export_nchw src=" << bref("A", 0, 6, 8, H / 2, W / 2) << " dst=" << bref("y", 0, 6, 8, H / 2, W / 2) << "\n";
+    accel_plan* p = nullptr;
+    if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
+    if ((rc = accel_model_write(t.m, "data", cur, ib, 0)) || (rc = accel_model_write(t.m, "data_key", prev, ib, 0))) return rc;
+    if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
+    return accel_model_read(t.m, "y", out, ob, 0);
+}

@@ -1,0 +1,84 @@
+// Internal kernel-launch interface of libaccel_hip (gfx950 only).
+// Activations are fp32 NHWC with a channel stride `Cs` (multiple of 4) that
+// may exceed the logical channel count (concat views, padded channels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct ConvParams {
+    const float* x;        // NHWC input view (channel offset already applied)
+    const float* w;        // packed weights [class][Cout_pad][K_pad]
+    float* y;              // NHWC output view
+    float* y2;             // optional second output: relu(v*scale2+shift2)
+    const float* res;      // optional residual, added before the activation
+    const float* scale; const float* shift;    // per output channel, length >= Cout_store
+    const float* scale2; const float* shift2;
+    int H, W;              // input spatial size
+    int Cin;               // channels per tap (multiple of 4)
+    int xCs;               // input channel stride
+    int Ho, Wo;            // GEMM pixel grid (deconv2x: = input grid)
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int K_pad;             // flattened K (kh*kw*Cin) rounded up to 32
+    int Cout_store;        // channels written (pad channels get exact zeros)
+    int yCs, y2Cs, resCs;
+    int M;                 // N*Ho*Wo
+    int act;               // 0 none, 1 relu, 2 leaky
+    float slope;
+    int deconv2x;          // 4x4 s2 p1 transposed conv as 4 sub-pixel 2x2 convs
+    int yH, yW;            // output spatial size (deconv2x addressing)
+    size_t w_class_stride; // floats between parity classes
+    int MT, NT;            // filled by the launcher
+    int force_tile;        // -1 = heuristic
+};
+
+hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
+int conv_pick_tile(const ConvParams& p);
+
+// ---- bandwidth-bound kernels (misc.hip) ---------------------------------------
+// NCHW fp32 3xHxW image -> NHWC4 (c3 = 0); optional per-channel scale/shift (bn_data)
+hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W,
+                           const float* scale3, const float* shift3, hipStream_t st);
+// FlowNet input: avgpool2x2(concat(cur/255, prev/255)) -> NHWC8 at H/2 x W/2 (c6,c7 = 0)
+hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W,
+                            hipStream_t st);
+
+struct PoolParams {
+    const float* x; float* y;
+    int C4;                // channel quads to process
+    int xCs, yCs;
+    int H, W, Ho, Wo;
+    int kh, kw, sh, sw, ph, pw;
+    int is_max;
+    const float* scale; const float* shift;   // optional BN epilogue
+    int relu;
+};
+hipError_t launch_pool(const PoolParams& p, hipStream_t st);
+
+// GridGenerator(warp)+BilinearSampler fused; flow is NHWC (ch0 = dx, ch1 = dy)
+hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs,
+                            float* out, int oCs, int C, int H, int W, hipStream_t st);
+
+struct DcnColsParams {
+    const float* x; const float* off; float* col;
+    int C, xCs, offCs, colCs;
+    int H, W, Ho, Wo;
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int dg;
+};
+hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st);
+
+struct ScoreTailParams {
+    const float* left;  int lCs;     // NHWC scores at H/16 x W/16
+    const float* right; int rCs;     // nullptr for single-head graphs
+    const float* wl; const float* wr;          // (ncls,1,32,32) deconvolution weights
+    const float* cw; const float* cb;          // (ncls, 2*ncls), (ncls)
+    float* logits;                   // NCHW ncls x H x W
+    unsigned char* labels;           // H x W
+    int ncls, Hs, Ws, H, W;
+};
+hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
+
+hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int H, int W, hipStream_t st);
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st);
+hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st);
+hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st);

@@ -1,0 +1,392 @@
+// Bandwidth-bound kernels of the Accel path (gfx950).  All of them are plain
+// HBM streaming / gather kernels: 16-byte per-lane accesses along the NHWC
+// channel axis (or along x for the NCHW boundary tensors), grid-stride free
+// (one element quad per thread, grids >> 256 CUs).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.h"
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// image boundary: NCHW 3xHxW -> NHWC4
+// ---------------------------------------------------------------------------
+__global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW,
+                                const float* scale, const float* shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    float r = src[i], g = src[HW + i], b = src[2 * HW + i];
+    if (scale) {
+        r = r * scale[0] + shift[0];
+        g = g * scale[1] + shift[1];
+        b = b * scale[2] + shift[2];
+    }
+    reinterpret_cast<float4*>(dst)[i] = make_float4(r, g, b, 0.f);
+}
+
+hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W, const float* scale3,
+                           const float* shift3, hipStream_t st)
+{
+    const int HW = H * W;
+    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, src, dst, HW, scale3, shift3);
+    return hipGetLastError();
+}
+
+// FlowNet input: Concat(cur/255, prev/255) -> avg pool 2x2/2  (ref get_flownet :1752-1753)
+__global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
+                                 float* __restrict__ dst, int H, int W)
+{
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const int oy = i / Wo, ox = i - oy * Wo;
+    const size_t HW = (size_t)H * W;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const float* pl = (c < 3 ? cur + c * HW : prev + (c - 3) * HW) + (size_t)(2 * oy) * W + 2 * ox;
+        const float2 t = *reinterpret_cast<const float2*>(pl);
+        const float2 b = *reinterpret_cast<const float2*>(pl + W);
+        float acc = 0.f;
+        acc += t.x / 255.0f; acc += t.y / 255.0f; acc += b.x / 255.0f; acc += b.y / 255.0f;
+        o[c] = acc / 4.0f;
+    }
+    o[6] = o[7] = 0.f;
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)i * 8);
+    d[0] = make_float4(o[0], o[1], o[2], o[3]);
+    d[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, hipStream_t st)
+{
+    const int n = (H / 2) * (W / 2);
+    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, cur, prev, dst, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Pooling (max 3x3/2 'full' or 'valid', avg 2x2/2), optional BN+ReLU epilogue
+// ---------------------------------------------------------------------------
+__global__ void pool_kernel(PoolParams p)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.Ho * p.Wo * p.C4;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % p.C4);
+    const int pix = (int)(idx / p.C4);
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    int hs = oy * p.sh - p.ph, ws = ox * p.sw - p.pw;
+    int he = min(hs + p.kh, p.H + p.ph), we = min(ws + p.kw, p.W + p.pw);
+    const int area = (he - hs) * (we - ws);
+    hs = max(hs, 0); ws = max(ws, 0); he = min(he, p.H); we = min(we, p.W);
+    float4 acc = p.is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = hs; iy < he; ++iy)
+        for (int ix = ws; ix < we; ++ix) {
+            const float4 v = *reinterpret_cast<const float4*>(p.x + ((size_t)iy * p.W + ix) * p.xCs + c4 * 4);
+            if (p.is_max) {
+                acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
+                acc.z = v.z > acc.z ? v.z : acc.z; acc.w = v.w > acc.w ? v.w : acc.w;
+            } else {
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    if (!p.is_max) {
+        const float a = (float)area;
+        acc.x /= a; acc.y /= a; acc.z /= a; acc.w /= a;
+    }
+    if (p.scale) {
+        const float4 s = *reinterpret_cast<const float4*>(p.scale + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.shift + c4 * 4);
+        acc.x = acc.x * s.x + b.x; acc.y = acc.y * s.y + b.y;
+        acc.z = acc.z * s.z + b.z; acc.w = acc.w * s.w + b.w;
+    }
+    if (p.relu) {
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+        acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(p.y + (size_t)pix * p.yCs + c4 * 4) = acc;
+}
+
+hipError_t launch_pool(const PoolParams& p, hipStream_t st)
+{
+    const long total = (long)p.Ho * p.Wo * p.C4;
+    hipLaunchKernelGGL(pool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Flow warp = GridGenerator(transform_type='warp') + BilinearSampler
+// (ref accel_18.py:174-175).  Same arithmetic sequence as the two MXNet ops:
+//   gx = (x + fx) / ((W-1)/2) - 1 ;  x_real = (gx + 1) * (W-1) / 2
+// In NHWC the four taps of a pixel are four contiguous channel rows, so the
+// gather is fully coalesced and needs no cross-lane shuffles.
+// ---------------------------------------------------------------------------
+__global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
+                                 const float* __restrict__ flow, int flCs,
+                                 float* __restrict__ out, int oCs, int C4, int H, int W)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)H * W * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int pix = (int)(idx / C4);
+    const int y = pix / W, x = pix - y * W;
+    const float2 f = *reinterpret_cast<const float2*>(flow + (size_t)pix * flCs);
+    const float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    const float gx = (f.x + (float)x) / sx - 1.0f;
+    const float gy = (f.y + (float)y) / sy - 1.0f;
+    const float y_real = (gy + 1) * (H - 1) / 2;
+    const float x_real = (gx + 1) * (W - 1) / 2;
+    const int ty = (int)floorf(y_real), tx = (int)floorf(x_real);
+    const float wy = 1.0f - (y_real - ty), wx = 1.0f - (x_real - tx);
+    const bool x0 = tx >= 0 && tx <= W - 1, x1 = tx + 1 >= 0 && tx + 1 <= W - 1;
+    const bool y0 = ty >= 0 && ty <= H - 1, y1 = ty + 1 >= 0 && ty + 1 <= H - 1;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tl = z, tr = z, bl = z, br = z;
+    const float* base = feat + c4 * 4;
+    if (x0 && y0) tl = *reinterpret_cast<const float4*>(base + ((size_t)ty * W + tx) * fCs);
+    if (x1 && y0) tr = *reinterpret_cast<const float4*>(base + ((size_t)ty * W + tx + 1) * fCs);
+    if (x0 && y1) bl = *reinterpret_cast<const float4*>(base + ((size_t)(ty + 1) * W + tx) * fCs);
+    if (x1 && y1) br = *reinterpret_cast<const float4*>(base + ((size_t)(ty + 1) * W + tx + 1) * fCs);
+    const float w00 = wy * wx, w01 = wy * (1.0f - wx), w10 = (1.0f - wy) * wx, w11 = (1.0f - wy) * (1.0f - wx);
+    float4 o;
+    // tl*wy*wx evaluates as (tl*wy)*wx in the reference expression; keep that association
+    o.x = tl.x * wy * wx + tr.x * wy * (1.0f - wx) + bl.x * (1.0f - wy) * wx + br.x * (1.0f - wy) * (1.0f - wx);
+    o.y = tl.y * wy * wx + tr.y * wy * (1.0f - wx) + bl.y * (1.0f - wy) * wx + br.y * (1.0f - wy) * (1.0f - wx);
+    o.z = tl.z * wy * wx + tr.z * wy * (1.0f - wx) + bl.z * (1.0f - wy) * wx + br.z * (1.0f - wy) * (1.0f - wx);
+    o.w = tl.w * wy * wx + tr.w * wy * (1.0f - wx) + bl.w * (1.0f - wy) * wx + br.w * (1.0f - wy) * (1.0f - wx);
+    (void)w00; (void)w01; (void)w10; (void)w11;
+    *reinterpret_cast<float4*>(out + (size_t)pix * oCs + c4 * 4) = o;
+}
+
+hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs, float* out, int oCs,
+                            int C, int H, int W, hipStream_t st)
+{
+    const int C4 = C / 4;
+    const long total = (long)H * W * C4;
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, feat, fCs, flow, flCs,
+                       out, oCs, C4, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Deformable im2col (DCN v1 sampling rule, see oracle/accel_oracle.c
+// orc_deform_im2col): writes col[pixel][tap][ci] (NHWC with 9*C channels) that
+// the implicit-GEMM kernel then contracts as a 1x1 convolution.
+// ---------------------------------------------------------------------------
+__global__ void dcn_cols_kernel(DcnColsParams p)
+{
+    const int C4 = p.C / 4, taps = p.kh * p.kw;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.Ho * p.Wo * taps * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int tap = (int)((idx / C4) % taps);
+    const int pix = (int)(idx / ((long)C4 * taps));
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    const int i = tap / p.kw, j = tap - i * p.kw;
+    const int cpg = p.C / p.dg;
+    const int g = (c4 * 4) / cpg;
+    const float2 o = *reinterpret_cast<const float2*>(p.off + (size_t)pix * p.offCs + g * 2 * taps + 2 * tap);
+    const float oh = o.x, ow = o.y;
+    const int h_in = oy * p.sh - p.ph, w_in = ox * p.sw - p.pw;
+    const float h_im = (float)(h_in + i * p.dh) + oh;
+    const float w_im = (float)(w_in + j * p.dw) + ow;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h_im >= 0 && w_im >= 0 && h_im < p.H && w_im < p.W) {
+        float h = (float)(i * p.dh) + oh, w = (float)(j * p.dw) + ow;
+        const int height = p.H - h_in, width = p.W - w_in;
+        int h_low = (int)floorf(h), w_low = (int)floorf(w);
+        int h_high, w_high;
+        if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else h_high = h_low + 1;
+        if (w_low >= width - 1) { w_high = w_low = width - 1; w = (float)w_low; } else w_high = w_low + 1;
+        const float lh = h - h_low, lw = w - w_low;
+        const float hh = 1 - lh, hw = 1 - lw;
+        // absolute coordinates, clamped only for memory safety (no effect on in-range samples)
+        const int y0 = min(max(h_in + h_low, 0), p.H - 1), y1 = min(max(h_in + h_high, 0), p.H - 1);
+        const int x0 = min(max(w_in + w_low, 0), p.W - 1), x1 = min(max(w_in + w_high, 0), p.W - 1);
+        const float* b = p.x + c4 * 4;
+        const float4 v1 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x0) * p.xCs);
+        const float4 v2 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x1) * p.xCs);
+        const float4 v3 = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x0) * p.xCs);
+        const float4 v4 = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x1) * p.xCs);
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        val.x = w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+        val.y = w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+        val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+        val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+    *reinterpret_cast<float4*>(p.col + (size_t)pix * p.colCs + (size_t)tap * p.C + c4 * 4) = val;
+}
+
+hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)
+{
+    const long total = (long)p.Ho * p.Wo * p.kh * p.kw * (p.C / 4);
+    hipLaunchKernelGGL(dcn_cols_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Fused score tail:
+//   Deconvolution 32x32/16 group=ncls (+Crop offset 8,8) of one or two score
+//   maps, Concat, `correction` 1x1 conv 2*ncls -> ncls (+bias), argmax.
+//   (ref accel_18.py:193-197,223-235; demo.py:238,245)
+// One thread per output pixel; logits are written NCHW (the boundary layout),
+// coalesced along x; the label map (first maximal index) is written alongside.
+// Accumulation orders match the oracle: deconv taps (ky asc, kx asc), then the
+// 1x1 conv over channels ascending on top of the bias.
+// ---------------------------------------------------------------------------
+template <int NCLS>
+__device__ __forceinline__ void upsample_px(const float* __restrict__ s, int Cs, const float* __restrict__ w,
+                                            int Hs, int Ws, int Y, int X, float* o)
+{
+    const int yy = Y + 8, xx = X + 8;
+    const int i0 = yy >> 4, ky0 = yy & 15, j0 = xx >> 4, kx0 = xx & 15;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {          // ky = ky0 (row i0), then ky0+16 (row i0-1)
+        const int i = i0 - a, ky = ky0 + 16 * a;
+        if (i < 0 || i >= Hs) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 - b, kx = kx0 + 16 * b;
+            if (j < 0 || j >= Ws) continue;
+            const float* sp = s + ((size_t)i * Ws + j) * Cs;
+            const float* wp = w + ky * 32 + kx;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) o[c] += wp[c * 1024] * sp[c];
+        }
+    }
+}
+
+template <int NCLS>
+__global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
+{
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= p.W || Y >= p.H) return;
+    float sl[NCLS], out[NCLS];
+    upsample_px<NCLS>(p.left, p.lCs, p.wl, p.Hs, p.Ws, Y, X, sl);
+    if (p.right) {
+        float sr[NCLS];
+        upsample_px<NCLS>(p.right, p.rCs, p.wr, p.Hs, p.Ws, Y, X, sr);
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) {
+            float v = p.cb[k];
+            const float* cw = p.cw + k * 2 * NCLS;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) v += cw[c] * sl[c];
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) v += cw[NCLS + c] * sr[c];
+            out[k] = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) out[k] = sl[k];
+    }
+    const size_t HW = (size_t)p.H * p.W, o = (size_t)Y * p.W + X;
+    int best = 0;
+    float bv = out[0];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) {
+        p.logits[k * HW + o] = out[k];
+        if (k > 0 && out[k] > bv) { bv = out[k]; best = k; }
+    }
+    p.labels[o] = (unsigned char)best;
+}
+
+hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st)
+{
+    dim3 grid(cdiv(p.W, 64), cdiv(p.H, 4));
+    if (p.ncls == 19) hipLaunchKernelGGL(score_tail_kernel<19>, grid, dim3(256), 0, st, p);
+    else if (p.ncls == 2) hipLaunchKernelGGL(score_tail_kernel<2>, grid, dim3(256), 0, st, p);
+    else if (p.ncls == 21) hipLaunchKernelGGL(score_tail_kernel<21>, grid, dim3(256), 0, st, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// layout converters for the NCHW boundary tensors (feat_key / warping_feat)
+// ---------------------------------------------------------------------------
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int Cs, float* __restrict__ dst, int C, int HW)
+{
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int pix = p0 + r, c = c0 + threadIdx.x;
+        tile[r][threadIdx.x] = (pix < HW && c < C) ? src[(size_t)pix * Cs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int c = c0 + r, pix = p0 + threadIdx.x;
+        if (pix < HW && c < C) dst[(size_t)c * HW + pix] = tile[threadIdx.x][r];
+    }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cs, int C, int HW)
+{
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int c = c0 + r, pix = p0 + threadIdx.x;
+        tile[r][threadIdx.x] = (pix < HW && c < C) ? src[(size_t)c * HW + pix] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int pix = p0 + r, c = c0 + threadIdx.x;
+        if (pix < HW && c < Cs) dst[(size_t)pix * Cs + c] = tile[threadIdx.x][r];   // pad channels get 0
+    }
+}
+
+hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int H, int W, hipStream_t st)
+{
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32)), dim3(32, 8), 0, st, src, Cs, dst, C, HW);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st)
+{
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(Cs, 32)), dim3(32, 8), 0, st, src, dst, Cs, C, HW);
+    return hipGetLastError();
+}
+
+__global__ void argmax_nchw_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int C, int HW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    int best = 0;
+    float bv = x[i];
+    for (int c = 1; c < C; ++c) {
+        const float v = x[(size_t)c * HW + i];
+        if (v > bv) { bv = v; best = c; }
+    }
+    out[i] = (unsigned char)best;
+}
+
+hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st)
+{
+    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, logits, labels, C, HW);
+    return hipGetLastError();
+}
+
+// strided NHWC view copy (C floats per pixel, C % 4 == 0): used to persist the
+// propagated feature when it was produced inside a concat buffer
+__global__ void copy_view_kernel(const float* __restrict__ src, int sCs, float* __restrict__ dst, int dCs, int C4, long total)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    const long pix = idx / C4;
+    *reinterpret_cast<float4*>(dst + pix * dCs + c4 * 4) = *reinterpret_cast<const float4*>(src + pix * sCs + c4 * 4);
+}
+
+hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st)
+{
+    const int C4 = (C + 3) / 4;
+    const long total = (long)HW * C4;
+    hipLaunchKernelGGL(copy_view_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sCs, dst, dCs, C4, total);
+    return hipGetLastError();
+}

@@ -1,0 +1,526 @@
+"""Lowering: MXNet-style symbol graph -> fused HIP kernel plan (text).
+
+This is where the MI355X design lives.  The reference hands its graph to
+MXNet, which runs one library kernel per operator over NCHW tensors (several
+hundred launches and ~3 GB of activation traffic per key frame).
+Here the graph is rewritten for the hardware before anything runs:
+
+  * activations are NHWC (channel stride padded to 4 floats) so every conv is an
+    implicit GEMM whose K axis is contiguous (16-byte loads, MFMA operands);
+  * BatchNorm (folded to scale/shift), bias, scalar multiply, residual add,
+    ReLU / LeakyReLU and the pre-activation BN+ReLU of the NEXT unit are fused
+    into the producing conv's epilogue (conv_igemm.hip);
+  * Concat never materialises: producers write straight into channel slices of
+    the concat buffer;
+  * Deconvolution 4x4/2 (+Crop offset 1) becomes four sub-pixel 2x2 convs;
+  * image/255 + Concat + avg-pool -> one `prep_flow` kernel; bn_data -> the
+    NCHW->NHWC4 image converter;
+  * GridGenerator + BilinearSampler -> one `warp` kernel;
+  * Deconvolution 32x32/16 + Crop + Concat + correction 1x1 + argmax -> one
+    `score_tail` kernel writing NCHW logits and the uint8 label map;
+  * activation buffers get static offsets in one arena from a liveness plan,
+    and the whole op list is captured into a hipGraph by the executor.
+
+The output is the plan text consumed by accel_model_add_plan()
+(accel_amd/csrc/accel_hip.cpp documents the line format).
+"""
+import numpy as np
+
+from .mx.symbol import infer_shapes
+
+ALIGN = 256
+
+
+def _r4(c):
+    return (c + 3) // 4 * 4
+
+
+class VBuf(object):
+    """A physical buffer: arena slot (offset assigned later) or persistent."""
+
+    def __init__(self, bid, Cs, H, W, space="A"):
+        self.id, self.Cs, self.H, self.W, self.space = bid, Cs, H, W, space
+        self.first, self.last = None, None
+        self.off = 0
+
+    @property
+    def nbytes(self):
+        return self.H * self.W * self.Cs * 4
+
+    def touch(self, op_idx):
+        if self.first is None:
+            self.first = op_idx
+        self.last = op_idx
+
+
+class View(object):
+    def __init__(self, buf, C, coff=0):
+        self.buf, self.C, self.coff = buf, C, coff
+
+    @property
+    def H(self):
+        return self.buf.H
+
+    @property
+    def W(self):
+        return self.buf.W
+
+    def ref(self):
+        return "%s:%d:%d:%d:%d:%d" % (self.buf.space, self.buf.off + self.coff * 4, self.C,
+                                      self.buf.Cs, self.buf.H, self.buf.W)
+
+
+class Lowering(object):
+    def __init__(self, sym, input_shapes, ncls=19, keep_feat_nchw=False):
+        self.sym = sym
+        self.shapes = infer_shapes(sym, input_shapes)
+        self.nodes = sym.topo()
+        self.heads = sym._heads()
+        self.head_ids = set(id(h) for h in self.heads)
+        self.ops = []          # (kind, dict, [views read], [views written])
+        self.bufs = []
+        self.pbufs = {}        # name -> bytes
+        self.val = {}          # id(node) -> View
+        self.absorbed = set()
+        self.concat_slot = {}  # id(node) -> View inside a concat buffer
+        self.outputs = {}      # output name -> descriptor
+        self.ncls = ncls
+        self.total_flops = 0.0
+        self.cons = {}
+        for n in self.nodes:
+            for idx, i in enumerate(n.inputs):
+                if n.op == "Crop" and idx == 1:
+                    continue   # shape reference only
+                self.cons.setdefault(id(i), []).append(n)
+        data_shape = input_shapes["data"]
+        self.H, self.W = int(data_shape[2]), int(data_shape[3])
+        for name in ("data", "data_key"):
+            self.pbufs[name] = 3 * self.H * self.W * 4
+
+    # ---- helpers ---------------------------------------------------------------
+    def shape(self, n):
+        return self.shapes[id(n)]
+
+    def consumers(self, n):
+        return self.cons.get(id(n), [])
+
+    def new_buf(self, C, H, W, Cs=None):
+        b = VBuf(len(self.bufs), Cs or _r4(C), H, W)
+        self.bufs.append(b)
+        return b
+
+    def pbuf_view(self, name, C, H, W, Cs=None):
+        Cs = Cs or _r4(C)
+        b = VBuf(-1, Cs, H, W, space=name)
+        self.pbufs[name] = max(self.pbufs.get(name, 0), H * W * Cs * 4)
+        return View(b, C)
+
+    def dest_for(self, node):
+        """Where the value of `node` must be written."""
+        if id(node) in self.concat_slot:
+            return self.concat_slot[id(node)]
+        _, C, H, W = self.shape(node)
+        if id(node) in self.head_ids and node.name == "res5c_relu":
+            return self.pbuf_view("feat", C, H, W)
+        return View(self.new_buf(C, H, W), C)
+
+    def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0):
+        idx = len(self.ops)
+        for v in list(reads) + list(writes):
+            if v is not None and v.buf.space == "A":
+                v.buf.touch(idx)
+        args = dict(args)
+        if flops:
+            args["flops"] = "%.6g" % flops
+            self.total_flops += flops
+        if nbytes:
+            args["bytes"] = "%.6g" % nbytes
+        self.ops.append((kind, args))
+
+    # ---- pre-pass: give Concat inputs their slices ---------------------------------
+    def plan_concats(self):
+        for n in self.nodes:
+            if n.op != "Concat":
+                continue
+            if all(i.op == "_div_scalar" for i in n.inputs):
+                continue    # FlowNet input concat -> prep_flow
+            if all(i.op == "Crop" and i.inputs[0].op == "Deconvolution" and
+                   i.inputs[0].attrs["kernel"] == (32, 32) for i in n.inputs):
+                continue    # score concat -> score_tail
+            _, C, H, W = self.shape(n)
+            buf = self.new_buf(C, H, W)
+            off = 0
+            for k, i in enumerate(n.inputs):
+                ci = self.shape(i)[1]
+                if off % 4:
+                    raise NotImplementedError("Concat %s: slice %d starts at channel %d (not 16-byte aligned)" % (n.name, k, off))
+                if id(i) in self.concat_slot:
+                    raise NotImplementedError("%s feeds two Concats" % i.name)
+                self.concat_slot[id(i)] = View(buf, ci, off)
+                off += ci
+            self.val[id(n)] = View(buf, C, 0)
+            self.absorbed.add(id(n))
+
+    # ---- image entry points ------------------------------------------------------------
+    def image_nhwc4(self, var, bn=None):
+        key = ("img", var.name, bn.name if bn is not None else None)
+        if key in self.val:
+            return self.val[key]
+        v = View(self.new_buf(3, self.H, self.W), 3)
+        args = {"src": "%s:0:3:4:%d:%d" % (var.name, self.H, self.W), "dst": v, "H": self.H, "W": self.W}
+        if bn is not None:
+            args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
+        self.emit("prep_rgb", args, [], [v], nbytes=(12 + 16) * self.H * self.W)
+        self.val[key] = v
+        return v
+
+    def input_view(self, node):
+        """View holding the value of `node` as a conv/pool input."""
+        if node.op == "null":
+            if node.name in ("data", "data_key"):
+                return self.image_nhwc4(node)
+            if node.name == "feat_key":
+                _, C, H, W = self.shape(node)
+                return self.pbuf_view("feat", C, H, W)
+            raise NotImplementedError("variable %s used as activation" % node.name)
+        if id(node) not in self.val:
+            raise NotImplementedError("value of %s (%s) was not materialised before use" % (node.name, node.op))
+        return self.val[id(node)]
+
+    # ---- conv-like anchors ----------------------------------------------------------------
+    def lower_anchor(self, A):
+        a = A.attrs
+        op = A.op
+        x = A.inputs[0]
+        mode = "conv"
+        if op == "Deconvolution":
+            if a["kernel"] != (4, 4) or a["stride"] != (2, 2) or a["num_group"] != 1 or a["pad"] not in ((0, 0), (1, 1)):
+                raise NotImplementedError("Deconvolution %s: only 4x4/2 pad 0|1 (and the 32x32/16 score upsampler)" % A.name)
+            mode = "deconv2x"
+        if op == "Convolution" and a["num_group"] != 1:
+            raise NotImplementedError("grouped Convolution %s" % A.name)
+        # BatchNorm on the raw image (bn_data) folds into the image converter
+        if x.op == "BatchNorm" and x.inputs[0].op == "null" and x.inputs[0].name in ("data", "data_key"):
+            xin = self.image_nhwc4(x.inputs[0], bn=x)
+            self.absorbed.add(id(x))
+        elif op == "DeformableConvolution":
+            xin = None
+        else:
+            xin = self.input_view(x)
+        widx = 2 if op == "DeformableConvolution" else 1
+        wname = A.inputs[widx].name
+        bias = None if a["no_bias"] else A.inputs[widx + 1].name
+
+        cur, bn, mul, res, act, slope = A, None, None, None, 0, 0.1
+        need_crop = mode == "deconv2x" and a["pad"] == (0, 0)
+        cropped = False
+        chain = []
+        while True:
+            if id(cur) in self.head_ids:
+                break
+            cons = self.consumers(cur)
+            if len(cons) != 1:
+                break
+            n = cons[0]
+            if need_crop and not cropped:
+                if n.op == "Crop" and n.attrs["offset"] == (1, 1) and cur is A:
+                    _, _, h, w = self.shape(n)
+                    _, _, hi, wi = self.shape(x)
+                    if (h, w) != (2 * hi, 2 * wi):
+                        raise NotImplementedError("Crop %s after 4x4/2 deconvolution must be exactly 2x the input" % n.name)
+                    cropped = True
+                    cur = n
+                    chain.append(n)
+                    continue
+                raise NotImplementedError("Deconvolution %s pad 0 must be followed by Crop(offset=(1,1))" % A.name)
+            if n.op == "BatchNorm" and bn is None and mul is None and res is None and act == 0:
+                bn = n
+            elif n.op == "_mul_scalar" and res is None and act == 0:
+                mul = (mul or 1.0) * n.attrs["scalar"]
+            elif n.op in ("broadcast_add", "elemwise_add") and res is None and act == 0:
+                other = n.inputs[1] if n.inputs[0] is cur else n.inputs[0]
+                if other.op != "null" and id(other) not in self.val:
+                    break
+                res = self.input_view(other)
+            elif n.op == "Activation" and n.attrs["act_type"] == "relu" and act == 0:
+                act = 1
+            elif n.op == "LeakyReLU" and n.attrs["act_type"] == "leaky" and act == 0:
+                act, slope = 2, n.attrs["slope"]
+            else:
+                break
+            cur = n
+            chain.append(n)
+        if need_crop and not cropped:
+            raise NotImplementedError("Deconvolution %s pad 0 without Crop" % A.name)
+
+        out = self.dest_for(cur)
+        # dual output: relu(bn(.)) of the value for the next pre-activation unit
+        out2, bn2, chain2 = None, None, []
+        if id(cur) not in self.head_ids or True:
+            for n in self.consumers(cur):
+                if n.op == "BatchNorm" and id(n) not in self.absorbed:
+                    c2 = self.consumers(n)
+                    if len(c2) == 1 and c2[0].op == "Activation" and c2[0].attrs["act_type"] == "relu" \
+                            and id(n) not in self.head_ids:
+                        bn2, r2 = n, c2[0]
+                        out2 = self.dest_for(r2)
+                        chain2 = [n, r2]
+                        break
+
+        _, cin, hi, wi = self.shape(x)
+        _, cout, ho, wo = self.shape(cur)
+        args = {"name": A.name, "out": out, "w": wname, "act": act, "slope": slope, "cin": cin, "cout": cout, "mode": mode}
+        reads = [res]
+        if op == "DeformableConvolution":
+            off = A.inputs[1]
+            xv, offv = self.input_view(x), self.input_view(off)
+            kh, kw = a["kernel"]
+            cp = _r4(cin)
+            cols = View(self.new_buf(kh * kw * cp, ho, wo), kh * kw * cp)
+            self.emit("dcn_cols", {"name": A.name + "_cols", "in": xv, "off": offv, "out": cols,
+                                   "k": "%d,%d" % a["kernel"], "s": "%d,%d" % a["stride"], "p": "%d,%d" % a["pad"],
+                                   "d": "%d,%d" % a["dilate"], "dg": a["num_deformable_group"]},
+                      [xv, offv], [cols], nbytes=4.0 * ho * wo * kh * kw * cp * 2)
+            args.update({"in": cols, "mode": "cols", "wk": "%d,%d" % a["kernel"], "k": "1,1"})
+            reads.append(cols)
+            flops = 2.0 * ho * wo * cout * cin * kh * kw
+        elif mode == "deconv2x":
+            args["in"] = xin
+            reads.append(xin)
+            flops = 2.0 * hi * wi * cout * cin * 16
+        else:
+            args.update({"in": xin, "k": "%d,%d" % a["kernel"], "s": "%d,%d" % a["stride"],
+                         "p": "%d,%d" % a["pad"], "d": "%d,%d" % a["dilate"]})
+            reads.append(xin)
+            flops = 2.0 * ho * wo * cout * cin * a["kernel"][0] * a["kernel"][1]
+        if bias:
+            args["bias"] = bias
+        if bn is not None:
+            args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
+        if mul is not None:
+            args["mul"] = mul
+        if res is not None:
+            args["res"] = res
+        writes = [out]
+        if out2 is not None:
+            args.update({"out2": out2, "bn2": bn2.name, "eps2": bn2.attrs["eps"], "fixg2": int(bn2.attrs["fix_gamma"])})
+            writes.append(out2)
+        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops)
+        self.absorbed.add(id(A))
+        for n in chain:
+            self.absorbed.add(id(n))
+            self.val[id(n)] = out
+        self.val[id(A)] = out
+        self.val[id(cur)] = out
+        for n in chain2:
+            self.absorbed.add(id(n))
+        if chain2:
+            self.val[id(chain2[-1])] = out2
+        self.finish_value(cur, out)
+
+    def finish_value(self, node, view):
+        """post-processing common to every materialised value"""
+        if id(node) in self.head_ids:
+            self.outputs[node.name + "_output"] = view
+
+    # ---- pooling ------------------------------------------------------------------------------
+    def lower_pool(self, P):
+        a = P.attrs
+        x = P.inputs[0]
+        if x.op == "Concat" and all(i.op == "_div_scalar" for i in x.inputs):
+            return self.lower_flow_input(P, x)
+        xin = self.input_view(x)
+        cur, bn, relu, chain = P, None, 0, []
+        while id(cur) not in self.head_ids:
+            cons = self.consumers(cur)
+            if len(cons) != 1:
+                break
+            n = cons[0]
+            if n.op == "BatchNorm" and bn is None and not relu:
+                bn = n
+            elif n.op == "Activation" and n.attrs["act_type"] == "relu" and not relu and bn is not None:
+                relu = 1
+            else:
+                break
+            cur = n
+            chain.append(n)
+        if bn is not None and not relu:
+            # BN without ReLU after a pool does not occur; keep the pool plain
+            cur, bn, chain = P, None, []
+        out = self.dest_for(cur)
+        args = {"name": P.name, "in": xin, "out": out, "kind": a["pool_type"], "k": "%d,%d" % a["kernel"],
+                "s": "%d,%d" % a["stride"], "p": "%d,%d" % a["pad"], "act": relu}
+        if bn is not None:
+            args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
+        _, c, ho, wo = self.shape(P)
+        _, _, hi, wi = self.shape(x)
+        self.emit("pool", args, [xin], [out], nbytes=4.0 * c * (hi * wi + ho * wo))
+        for n in [P] + chain:
+            self.absorbed.add(id(n))
+            self.val[id(n)] = out
+        self.finish_value(cur, out)
+
+    def lower_flow_input(self, P, cat):
+        a = P.attrs
+        if a["pool_type"] != "avg" or a["kernel"] != (2, 2) or a["stride"] != (2, 2) or a["pad"] != (0, 0):
+            raise NotImplementedError("FlowNet input pooling must be avg 2x2/2")
+        srcs = []
+        for d in cat.inputs:
+            if abs(d.attrs["scalar"] - 255.0) > 0 or d.inputs[0].op != "null":
+                raise NotImplementedError("FlowNet input must be image / 255.0")
+            srcs.append(d.inputs[0].name)
+            self.absorbed.add(id(d))
+        self.absorbed.add(id(cat))
+        out = View(self.new_buf(6, self.H // 2, self.W // 2, Cs=8), 6)
+        self.emit("prep_flow", {"cur": "%s:0:3:4:%d:%d" % (srcs[0], self.H, self.W),
+                                "prev": "%s:0:3:4:%d:%d" % (srcs[1], self.H, self.W),
+                                "dst": out, "H": self.H, "W": self.W}, [], [out],
+                  nbytes=24.0 * self.H * self.W + 8.0 * self.H * self.W)
+        self.absorbed.add(id(P))
+        self.val[id(P)] = out
+
+    # ---- warp ---------------------------------------------------------------------------------------
+    def lower_warp(self, B):
+        feat, grid = B.inputs
+        if grid.op != "GridGenerator":
+            raise NotImplementedError("BilinearSampler grid must come from GridGenerator(warp)")
+        flow = self.input_view(grid.inputs[0])
+        fin = self.input_view(feat)
+        out = self.dest_for(B)
+        _, C, H, W = self.shape(B)
+        self.emit("warp", {"name": B.name, "feat": fin, "flow": flow, "out": out}, [fin, flow], [out],
+                  nbytes=2.0 * 4 * C * H * W + 8.0 * H * W)
+        self.absorbed.update((id(B), id(grid)))
+        self.val[id(B)] = out
+        if id(B) in self.head_ids:
+            # the propagated feature: becomes `feat` for the next frame (demo.py:241-243)
+            dst = self.pbuf_view("feat", C, H, W)
+            self.emit("copy", {"src": out, "dst": dst}, [out], [dst], nbytes=8.0 * C * H * W)
+            self.outputs[B.name + "_output"] = dst
+
+    # ---- score tail --------------------------------------------------------------------------------
+    @staticmethod
+    def _is_upsampler(n):
+        return n.op == "Deconvolution" and n.attrs["kernel"] == (32, 32) and n.attrs["stride"] == (16, 16) \
+            and n.attrs["num_group"] == n.attrs["num_filter"] and n.attrs["pad"] == (0, 0) and n.attrs["no_bias"]
+
+    def _tail_branch(self, crop):
+        if crop.op != "Crop" or crop.attrs["offset"] != (8, 8) or not self._is_upsampler(crop.inputs[0]):
+            return None
+        up = crop.inputs[0]
+        _, n, h, w = self.shape(crop)
+        if (h, w) != (self.H, self.W) or self.shape(up.inputs[0])[2:] != (self.H // 16, self.W // 16):
+            raise NotImplementedError("score upsampling must map H/16 x W/16 scores onto the full image")
+        return up
+
+    def lower_tail(self, node, crops, corr=None):
+        ups = [self._tail_branch(c) for c in crops]
+        if any(u is None for u in ups):
+            raise NotImplementedError("unsupported score tail at %s" % node.name)
+        ncls = ups[0].attrs["num_filter"]
+        logits = self.pbuf_view("logits", ncls, self.H, self.W, Cs=4)
+        self.pbufs["logits"] = ncls * self.H * self.W * 4
+        labels = self.pbuf_view("labels", 1, self.H, self.W, Cs=4)
+        self.pbufs["labels"] = (self.H * self.W + 255) // 256 * 256
+        left = self.input_view(ups[0].inputs[0])
+        args = {"name": node.name, "left": left, "wl": ups[0].inputs[1].name, "H": self.H, "W": self.W, "ncls": ncls,
+                "logits": "logits:0:%d:4:%d:%d" % (ncls, self.H, self.W), "labels": "labels:0:1:4:%d:%d" % (self.H, self.W)}
+        reads = [left]
+        flops = 0.0
+        if corr is not None:
+            right = self.input_view(ups[1].inputs[0])
+            args.update({"right": right, "wr": ups[1].inputs[1].name, "cw": corr.inputs[1].name, "cb": corr.inputs[2].name})
+            reads.append(right)
+            flops = 2.0 * ncls * 2 * ncls * self.H * self.W
+        self.emit("score_tail", args, reads, [], flops=flops, nbytes=4.0 * ncls * self.H * self.W + self.H * self.W)
+        for n in [node] + list(crops) + ups + ([corr] if corr is not None else []):
+            self.absorbed.add(id(n))
+        self.outputs[node.name + "_output"] = "logits"
+
+    # ---- driver ---------------------------------------------------------------------------------------
+    def run(self):
+        self.plan_concats()
+        for n in self.nodes:
+            if id(n) in self.absorbed or n.op in ("null", "_group"):
+                continue
+            op = n.op
+            if op == "Deconvolution" and self._is_upsampler(n):
+                continue
+            if op == "Crop" and self._is_upsampler(n.inputs[0]):
+                if id(n) in self.head_ids:
+                    self.lower_tail(n, [n])
+                continue
+            if op == "Concat":
+                continue   # score concat; handled at the correction conv
+            if op == "Convolution" and n.inputs[0].op == "Concat" and id(n.inputs[0]) not in self.val:
+                cat = n.inputs[0]
+                if a_is_1x1(n) and len(cat.inputs) == 2:
+                    self.lower_tail(n, cat.inputs, corr=n)
+                    self.absorbed.add(id(cat))
+                    continue
+                raise NotImplementedError("Convolution %s over an unsupported Concat" % n.name)
+            if op in ("Convolution", "Deconvolution", "DeformableConvolution"):
+                self.lower_anchor(n)
+            elif op == "Pooling":
+                self.lower_pool(n)
+            elif op == "BilinearSampler":
+                self.lower_warp(n)
+            elif op in ("_div_scalar", "GridGenerator"):
+                continue   # absorbed by prep_flow / warp when their consumer is lowered
+            elif op == "BatchNorm" and n.inputs[0].op == "null":
+                continue   # bn_data: folded when its conv is lowered
+            else:
+                raise NotImplementedError("no lowering for %s (%s): not produced by a fusable anchor" % (n.name, op))
+        for h in self.heads:
+            if h.op == "null":
+                self.outputs[h.name] = "input:" + h.name
+        self.assign_offsets()
+        return self
+
+    def assign_offsets(self):
+        """Greedy first-fit arena packing over [first, last] op-index lifetimes."""
+        live = [b for b in self.bufs if b.first is not None]
+        live.sort(key=lambda b: -b.nbytes)
+        placed = []
+        total = 0
+        for b in live:
+            size = (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
+            taken = sorted((p.off, p.off + (p.nbytes + ALIGN - 1) // ALIGN * ALIGN) for p in placed
+                           if not (p.last < b.first or b.last < p.first))
+            off = 0
+            for s, e in taken:
+                if off + size <= s:
+                    break
+                off = max(off, e)
+            b.off = off
+            placed.append(b)
+            total = max(total, off + size)
+        self.arena_bytes = total
+
+    def text(self, graph=True):
+        lines = ["# accel_amd plan: %d ops, arena %.1f MB, %.2f GFLOP" % (len(self.ops), self.arena_bytes / 1e6, self.total_flops / 1e9)]
+        if not graph:
+            lines.append("option graph=0")
+        lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
+        for name, nbytes in sorted(self.pbufs.items()):
+            lines.append("pbuf name=%s bytes=%d" % (name, nbytes))
+        for kind, args in self.ops:
+            toks = [kind]
+            for k, v in args.items():
+                if isinstance(v, View):
+                    v = v.ref()
+                elif isinstance(v, float):
+                    v = repr(v)
+                toks.append("%s=%s" % (k, v))
+            lines.append(" ".join(toks))
+        return "\n".join(lines) + "\n"
+
+
+def a_is_1x1(n):
+    a = n.attrs
+    return a["kernel"] == (1, 1) and a["stride"] == (1, 1) and a["pad"] == (0, 0) and not a["no_bias"]
+
+
+def lower(sym, input_shapes, graph=True):
+    lw = Lowering(sym, input_shapes).run()
+    return lw.text(graph=graph), lw

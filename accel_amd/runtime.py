@@ -1,0 +1,290 @@
+"""ctypes binding of libaccel_hip.so (include/accel_hip.h).
+
+The library is the only compute path of accel_amd: there is no CPU fallback.
+If it is missing or no MI355X is visible, every call raises AccelError.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaccel_hip.so")
+_lib = None
+
+
+class AccelError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        for f in os.listdir(src):
+            if f.endswith((".hip", ".cpp", ".h")) and os.path.getmtime(os.path.join(src, f)) > t:
+                stale = True
+        hdr = os.path.join(_HERE, "..", "include", "accel_hip.h")
+        if os.path.exists(hdr) and os.path.getmtime(hdr) > t:
+            stale = True
+    if stale:
+        subprocess.check_call(["make", "-C", src, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _declare(lib):
+    c = ctypes
+    vp, i, f, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
+    lib.accel_last_error.restype = c.c_char_p
+    lib.accel_version.restype = c.c_char_p
+    lib.accel_ctx_stream.restype = vp
+    lib.accel_ctx_stream.argtypes = [vp]
+    sigs = {
+        "accel_ctx_create": [i, c.POINTER(vp)],
+        "accel_ctx_destroy": [vp],
+        "accel_sync": [vp],
+        "accel_model_create": [vp, c.POINTER(vp)],
+        "accel_model_destroy": [vp],
+        "accel_model_set_param": [vp, c.c_char_p, vp, i, c.POINTER(c.c_int64)],
+        "accel_model_has_param": [vp, c.c_char_p],
+        "accel_model_add_plan": [vp, c.c_char_p, c.c_char_p, c.POINTER(vp)],
+        "accel_plan_finalize": [vp],
+        "accel_plan_run": [vp],
+        "accel_plan_num_ops": [vp],
+        "accel_plan_op_info": [vp, i, c.c_char_p, c.c_char_p, c.POINTER(c.c_double), c.POINTER(c.c_double)],
+        "accel_plan_profile": [vp, i, vp, i],
+        "accel_model_write": [vp, c.c_char_p, vp, sz, i],
+        "accel_model_read": [vp, c.c_char_p, vp, sz, i],
+        "accel_model_buffer": [vp, c.c_char_p, c.POINTER(vp), c.POINTER(sz)],
+        "accel_key_forward": [vp, vp, i, vp, vp, vp, i],
+        "accel_cur_forward": [vp, vp, vp, i, vp, vp, vp, i],
+        "accel_conv2d": [vp, vp, i, i, i, i, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp, vp, i, f, i, vp],
+        "accel_deconv2d_4x4s2": [vp, vp, i, i, i, i, vp, vp, i, i, f, vp],
+        "accel_deform_conv2d": [vp, vp, i, i, i, i, vp, vp, i, i, i, i, i, i, i, i, i, i, vp],
+        "accel_pool2d": [vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, vp, vp, i, vp],
+        "accel_flow_warp": [vp, vp, i, i, i, vp, vp],
+        "accel_score_fuse": [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp],
+        "accel_argmax_c": [vp, vp, i, i, i, vp],
+        "accel_flow_input": [vp, vp, vp, i, i, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i
+    return sigs
+
+
+EXPORTS = None
+
+
+def lib():
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AccelError("libaccel_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                             "accel_amd has no CPU fallback")
+        _lib = ctypes.CDLL(LIB_PATH)
+        EXPORTS = _declare(_lib)
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AccelError("libaccel_hip: %s (code %d)" % (lib().accel_last_error().decode(), rc))
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context(object):
+    def __init__(self, device_id=0):
+        self.handle = ctypes.c_void_p()
+        check(lib().accel_ctx_create(int(device_id), ctypes.byref(self.handle)))
+        self.device_id = int(device_id)
+
+    def sync(self):
+        check(lib().accel_sync(self.handle))
+
+    @property
+    def stream(self):
+        return lib().accel_ctx_stream(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib().accel_ctx_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    # ---- operator level (host NCHW fp32 in/out) --------------------------------
+    def conv2d(self, x, w, bias=None, stride=1, pad=0, dilate=1, scale=None, shift=None,
+               residual=None, act=0, slope=0.1, tile=-1):
+        x, w = _f32(x), _f32(w)
+        N, C, H, W = x.shape
+        K, _, kh, kw = w.shape
+        p2 = lambda v: (v, v) if np.isscalar(v) else tuple(v)
+        (sh, sw), (ph, pw), (dh, dw) = p2(stride), p2(pad), p2(dilate)
+        Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+        Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+        y = np.empty((N, K, Ho, Wo), np.float32)
+        keep = [None if a is None else _f32(a) for a in (bias, scale, shift, residual)]
+        ptr = [None if a is None else _fp(a) for a in keep]
+        check(lib().accel_conv2d(self.handle, _fp(x), N, C, H, W, _fp(w), ptr[0], K, kh, kw, sh, sw, ph, pw,
+                                 dh, dw, ptr[1], ptr[2], ptr[3], int(act), float(slope), int(tile), _fp(y)))
+        return y
+
+    def deconv2d_4x4s2(self, x, w, bias=None, act=0, slope=0.1):
+        x, w = _f32(x), _f32(w)
+        N, C, H, W = x.shape
+        K = w.shape[1]
+        y = np.empty((N, K, 2 * H, 2 * W), np.float32)
+        b = None if bias is None else _f32(bias)
+        check(lib().accel_deconv2d_4x4s2(self.handle, _fp(x), N, C, H, W, _fp(w), None if b is None else _fp(b),
+                                         K, int(act), float(slope), _fp(y)))
+        return y
+
+    def deform_conv2d(self, x, offset, w, stride=1, pad=0, dilate=1, dg=1):
+        x, offset, w = _f32(x), _f32(offset), _f32(w)
+        N, C, H, W = x.shape
+        K, _, kh, kw = w.shape
+        Ho = (H + 2 * pad - dilate * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dilate * (kw - 1) - 1) // stride + 1
+        y = np.empty((N, K, Ho, Wo), np.float32)
+        check(lib().accel_deform_conv2d(self.handle, _fp(x), N, C, H, W, _fp(offset), _fp(w), K, kh, kw,
+                                        stride, stride, pad, pad, dilate, dilate, dg, _fp(y)))
+        return y
+
+    def pool2d(self, x, kind, kernel, stride, pad=0, convention="valid", scale=None, shift=None, relu=False):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        full = convention == "full"
+        po = lambda n: (1 + -(-(n + 2 * pad - kernel) // stride)) if full else (1 + (n + 2 * pad - kernel) // stride)
+        y = np.empty((N, C, po(H), po(W)), np.float32)
+        s = None if scale is None else _f32(scale)
+        b = None if shift is None else _f32(shift)
+        check(lib().accel_pool2d(self.handle, _fp(x), N, C, H, W, int(kind == "max"), int(full), kernel, kernel,
+                                 stride, stride, pad, pad, None if s is None else _fp(s),
+                                 None if b is None else _fp(b), int(relu), _fp(y)))
+        return y
+
+    def flow_warp(self, feat, flow):
+        feat, flow = _f32(feat), _f32(flow)
+        _, C, H, W = feat.shape
+        out = np.empty_like(feat)
+        check(lib().accel_flow_warp(self.handle, _fp(feat), C, H, W, _fp(flow), _fp(out)))
+        return out
+
+    def score_fuse(self, left, wl, right=None, wr=None, cw=None, cb=None):
+        left, wl = _f32(left), _f32(wl)
+        _, ncls, Hs, Ws = left.shape
+        logits = np.empty((1, ncls, 16 * Hs, 16 * Ws), np.float32)
+        labels = np.empty((1, 16 * Hs, 16 * Ws), np.uint8)
+        opt = [None if a is None else _f32(a) for a in (right, wr, cw, cb)]
+        ptr = [None if a is None else _fp(a) for a in opt]
+        check(lib().accel_score_fuse(self.handle, _fp(left), ptr[0], ncls, Hs, Ws, _fp(wl), ptr[1], ptr[2], ptr[3],
+                                     _fp(logits), _fp(labels)))
+        return logits, labels
+
+    def argmax_c(self, logits):
+        logits = _f32(logits)
+        _, C, H, W = logits.shape
+        labels = np.empty((1, H, W), np.uint8)
+        check(lib().accel_argmax_c(self.handle, _fp(logits), C, H, W, _fp(labels)))
+        return labels
+
+    def flow_input(self, cur, prev):
+        cur, prev = _f32(cur), _f32(prev)
+        _, _, H, W = cur.shape
+        out = np.empty((1, 6, H // 2, W // 2), np.float32)
+        check(lib().accel_flow_input(self.handle, _fp(cur), _fp(prev), H, W, _fp(out)))
+        return out
+
+
+class Plan(object):
+    def __init__(self, model, handle, role):
+        self.model, self.handle, self.role = model, handle, role
+
+    def finalize(self):
+        check(lib().accel_plan_finalize(self.handle))
+
+    def run(self):
+        check(lib().accel_plan_run(self.handle))
+
+    def ops(self):
+        n = lib().accel_plan_num_ops(self.handle)
+        out = []
+        kind = ctypes.create_string_buffer(32)
+        name = ctypes.create_string_buffer(64)
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        for i in range(n):
+            check(lib().accel_plan_op_info(self.handle, i, kind, name, ctypes.byref(fl), ctypes.byref(by)))
+            out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value})
+        return out
+
+    def profile(self, iters=3):
+        n = lib().accel_plan_num_ops(self.handle)
+        ms = np.zeros(n, np.float32)
+        check(lib().accel_plan_profile(self.handle, int(iters), _fp(ms), n))
+        return ms
+
+
+class Model(object):
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.handle = ctypes.c_void_p()
+        check(lib().accel_model_create(ctx.handle, ctypes.byref(self.handle)))
+        self.plans = {}
+
+    def set_param(self, name, arr):
+        a = _f32(arr)
+        shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+        check(lib().accel_model_set_param(self.handle, name.encode(), _fp(a), a.ndim, shape))
+
+    def set_params(self, *dicts):
+        for d in dicts:
+            for k, v in d.items():
+                self.set_param(k, v.asnumpy() if hasattr(v, "asnumpy") else v)
+
+    def add_plan(self, role, text):
+        h = ctypes.c_void_p()
+        check(lib().accel_model_add_plan(self.handle, role.encode(), text.encode(), ctypes.byref(h)))
+        p = Plan(self, h, role)
+        self.plans[role] = p
+        return p
+
+    def write(self, buf, arr):
+        a = np.ascontiguousarray(arr)
+        check(lib().accel_model_write(self.handle, buf.encode(), _fp(a), a.nbytes, 0))
+
+    def write_device(self, buf, dev_ptr, nbytes):
+        check(lib().accel_model_write(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
+
+    def read(self, buf, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        check(lib().accel_model_read(self.handle, buf.encode(), _fp(out), out.nbytes, 0))
+        return out
+
+    def buffer(self, buf):
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().accel_model_buffer(self.handle, buf.encode(), ctypes.byref(ptr), ctypes.byref(n)))
+        return ptr.value, n.value
+
+    def key_forward(self, img=None):
+        check(lib().accel_key_forward(self.handle, None if img is None else _fp(_f32(img)), 0, None, None, None, 0))
+
+    def cur_forward(self, img_cur=None, img_prev=None):
+        a = None if img_cur is None else _f32(img_cur)
+        b = None if img_prev is None else _f32(img_prev)
+        check(lib().accel_cur_forward(self.handle, None if a is None else _fp(a), None if b is None else _fp(b),
+                                      0, None, None, None, 0))
+
+    def close(self):
+        if self.handle:
+            lib().accel_model_destroy(self.handle)
+            self.handle = ctypes.c_void_p()

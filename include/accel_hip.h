@@ -1,0 +1,133 @@
+/*
+ * accel_hip.h -- C ABI of libaccel_hip.so, the MI355X (gfx950) execution engine
+ * of the Accel (dff_deeplab) video-segmentation inference path.
+ *
+ * What it replaces in the reference (SamvitJ/Accel, /root/reference):
+ *   the reference has NO C ABI on this path; its Python symbol files describe a
+ *   graph and MXNet (un-vendored, README.md:76) executes it.  The boundary a
+ *   maintainer binds is therefore the executor contract of
+ *     dff_deeplab/core/tester.py:22-35        Predictor(bind, init_params, forward, get_outputs)
+ *     dff_deeplab/core/module.py:791-845,1011-1044  bind at max shape / forward
+ *     dff_deeplab/core/DataParallelExecutorGroup.py:18-27,330-378  copy-in, forward, collect
+ *   and, per operator, the MXNet ops the symbol files call
+ *     (dff_deeplab/symbols/resnet_v1_101_flownet_deeplab.py, accel_18.py:121-239).
+ *   Each entry point below names the reference interface it stands in for.
+ *
+ * Conventions: every function returns 0 on success and a negative code on
+ * failure (never throws, never prints); accel_last_error() gives the message of
+ * the last failure on the calling thread.  Tensors crossing the boundary are
+ * fp32 NCHW (label maps uint8 HxW), exactly the reference's layouts; `on_device`
+ * flags whether a caller pointer is HBM or host memory.  The caller owns all
+ * I/O buffers; the library owns weights, the activation arena and the named
+ * persistent buffers.  Calls enqueue on the context's HIP stream; only
+ * accel_sync() and copies to host memory block.  Objects are re-entrant across
+ * instances, not thread-safe within one instance (same as one MXNet executor).
+ */
+#ifndef ACCEL_HIP_H
+#define ACCEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct accel_ctx accel_ctx;       /* one GPU + one HIP stream            */
+typedef struct accel_model accel_model;   /* parameters + persistent buffers     */
+typedef struct accel_plan accel_plan;     /* one bound graph (key or cur)        */
+
+#define ACCEL_OK 0
+#define ACCEL_ERR_ARG (-1)
+#define ACCEL_ERR_HIP (-2)
+#define ACCEL_ERR_PLAN (-3)
+#define ACCEL_ERR_PARAM (-4)
+
+const char* accel_last_error(void);
+const char* accel_version(void);
+
+/* context: stands in for `context=[mx.gpu(i)]` (demo.py:197,201) */
+int accel_ctx_create(int device_id, accel_ctx** out);
+int accel_ctx_destroy(accel_ctx* ctx);
+int accel_sync(accel_ctx* ctx);                       /* = NDArray.asnumpy()'s implicit wait */
+void* accel_ctx_stream(accel_ctx* ctx);               /* hipStream_t, for interop (RCCL / torch ExternalStream) */
+
+/* model: parameter store shared by the key and cur graphs
+ * (demo.py:192-195 arg_params/aux_params dicts; tester.py:30 init_params) */
+int accel_model_create(accel_ctx* ctx, accel_model** out);
+int accel_model_destroy(accel_model* m);
+/* name = MXNet parameter name (`arg:`/`aux:` prefix already stripped), data = fp32
+ * host memory in MXNet layout (OIHW conv, (Cin,Cout/g,kh,kw) deconv, (C,) BN);
+ * the library repacks at plan finalisation. */
+int accel_model_set_param(accel_model* m, const char* name, const float* data,
+                          int ndim, const int64_t* shape);
+int accel_model_has_param(accel_model* m, const char* name);
+
+/* plan: a lowered, fused kernel sequence (text form, produced by
+ * accel_amd/lower.py from the symbol graph) bound to static shapes -- the
+ * counterpart of Module.bind (module.py:791-845).  `role` is "key", "cur" or any
+ * label; plans of one model share the model's persistent buffers by name. */
+int accel_model_add_plan(accel_model* m, const char* role, const char* plan_text, accel_plan** out);
+int accel_plan_finalize(accel_plan* p);   /* repack weights, allocate arena, capture hipGraph */
+int accel_plan_run(accel_plan* p);        /* enqueue one forward (Module.forward, module.py:1011) */
+int accel_plan_num_ops(accel_plan* p);
+/* kind: up to 31 chars + NUL; flops/bytes: algorithmic work of op i (0 if n/a) */
+int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double* flops, double* bytes);
+/* runs the plan `iters` times eagerly with a HIP event pair around every op on
+ * the context stream; ms[i] = mean duration of op i */
+int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);
+
+/* persistent buffers (inputs `data`/`data_key`, outputs `logits`/`labels`, the
+ * propagated feature `feat`): DataParallelExecutorGroup._load_general copy-in
+ * (:18-27) and get_outputs (:357-378) */
+int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device);
+int accel_model_read(accel_model* m, const char* buf, void* dst, size_t bytes, int dst_on_device);
+int accel_model_buffer(accel_model* m, const char* buf, void** dev_ptr, size_t* bytes);
+
+/* whole-frame entry points, the two Predictor.predict calls of the demo loop
+ * (demo.py:235-245; tester.py:158-171 im_segment).  img_*: fp32 1x3xHxW already
+ * mean-subtracted (lib/utils/image.py:224-235).  Any output pointer may be NULL.
+ * feat_out / logits_out are NCHW fp32, labels_out uint8 HxW (first-max argmax).
+ * The propagated feature stays in HBM between calls. */
+int accel_key_forward(accel_model* m, const float* img, int img_on_device,
+                      float* feat_out, float* logits_out, uint8_t* labels_out, int out_on_device);
+int accel_cur_forward(accel_model* m, const float* img_cur, const float* img_prev, int img_on_device,
+                      float* feat_out, float* logits_out, uint8_t* labels_out, int out_on_device);
+
+/* ---- operator level (host fp32 NCHW in / out; used by the parity tests) --------
+ * Each is the single MXNet operator named, run through the same kernels and the
+ * same weight repacking as the plans. */
+/* mx.symbol.Convolution (+ optional per-channel scale/shift, residual, activation:
+ * the fused epilogue).  act: 0 none, 1 relu, 2 leaky(slope). */
+int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                 const float* w, const float* bias, int K, int kh, int kw,
+                 int sh, int sw, int ph, int pw, int dh, int dw,
+                 const float* scale, const float* shift, const float* residual,
+                 int act, float slope, int force_tile, float* y);
+/* mx.symbol.Deconvolution 4x4 stride 2 pad 1 (== pad 0 + Crop(offset 1,1)) */
+int accel_deconv2d_4x4s2(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                         const float* w, const float* bias, int K, int act, float slope, float* y);
+/* mx.contrib.symbol.DeformableConvolution, no bias */
+int accel_deform_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
+                        const float* offset, const float* w, int K, int kh, int kw,
+                        int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* y);
+/* mx.symbol.Pooling; optional BN scale/shift + relu epilogue */
+int accel_pool2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W, int is_max, int full,
+                 int kh, int kw, int sh, int sw, int ph, int pw,
+                 const float* scale, const float* shift, int relu, float* y);
+/* GridGenerator(transform_type='warp') + BilinearSampler == the "FlowWarp" op */
+int accel_flow_warp(accel_ctx* ctx, const float* feat, int C, int H, int W, const float* flow, float* out);
+/* Deconvolution 32x32/16 group=ncls + Crop(8,8) [+ Concat + correction 1x1] + argmax.
+ * right/wr/cw/cb may be NULL (single head). Hs,Ws = score size; output H=16*Hs, W=16*Ws */
+int accel_score_fuse(accel_ctx* ctx, const float* left, const float* right, int ncls, int Hs, int Ws,
+                     const float* wl, const float* wr, const float* cw, const float* cb,
+                     float* logits, uint8_t* labels);
+/* mx.ndarray.argmax(axis=1) of an NCHW tensor (first maximal index) */
+int accel_argmax_c(accel_ctx* ctx, const float* logits, int C, int H, int W, uint8_t* labels);
+/* FlowNet input stage: avgpool2(concat(cur/255, prev/255)) -> 6 x H/2 x W/2 */
+int accel_flow_input(accel_ctx* ctx, const float* cur, const float* prev, int H, int W, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""Functional CPU restatement of the Accel test-time graphs, written directly
+from the reference's symbol files (not from accel_amd's graph builder, so the
+two descriptions check one another).
+
+TEST INFRASTRUCTURE ONLY / PARITY UNPINNED -- see oracle/accel_oracle.c.
+
+`P` everywhere is a dict {mxnet parameter name: fp32 numpy array} holding both
+arg and aux params (names never collide: demo.py:192-195 merges them the same
+way).  All tensors are NCHW fp32.
+"""
+import numpy as np
+
+from . import ops as O
+
+EPS_DCN = 1e-5      # self.eps, resnet_v1_101_flownet_deeplab.py:23
+EPS_PREACT = 2e-5   # residual_unit / resnet(), :50-75,108
+
+
+def _bn(P, name, x, eps, fix_gamma=False):
+    return O.batchnorm(x, P[name + "_gamma"], P[name + "_beta"],
+                       P[name + "_moving_mean"], P[name + "_moving_var"], eps, fix_gamma)
+
+
+def _conv(P, name, x, stride=1, pad=0, dilate=1, bias=False, wname=None, bname=None):
+    w = P[wname or name + "_weight"]
+    b = P[bname or name + "_bias"] if bias else None
+    return O.conv2d(x, w, b, stride, pad, dilate)
+
+
+# --------------------------------------------------------------------------
+# ResNet-101 / ResNet-50 with deformable res5
+# resnet_v1_101_flownet_deeplab.py:576-1300 (get_resnet_dcn), :235-574 (get_resnet_dcn_50)
+# --------------------------------------------------------------------------
+def resnet_dcn_bottleneck(P, data, units, prefix, unit_namer, dcn_dg, offset_dilated):
+    p = prefix
+    x = _conv(P, p + "conv1", data, stride=2, pad=3)
+    x = O.relu(_bn(P, p + "bn_conv1", x, EPS_DCN))
+    x = O.pool2d(x, "max", 3, 2, 0, "full")
+    mids = [64, 128, 256, 512]
+    for si, n in enumerate(units):
+        stage = si + 2
+        for ui, suffix in enumerate(unit_namer(stage, n)):
+            u = "%d%s" % (stage, suffix)
+            first = ui == 0
+            # stride 2 sits on the 1x1 convs of res3a / res4a (:647-652,:734-739); res5 keeps stride 1
+            s = 2 if (first and stage in (3, 4)) else 1
+            if first:
+                sc = _bn(P, p + "bn" + u + "_branch1",
+                         _conv(P, p + "res" + u + "_branch1", x, stride=s), EPS_DCN)
+            else:
+                sc = x
+            y = _conv(P, p + "res" + u + "_branch2a", x, stride=s)
+            y = O.relu(_bn(P, p + "bn" + u + "_branch2a", y, EPS_DCN))
+            if stage == 5:
+                oname = p + "res" + u + "_branch2b_offset"
+                if offset_dilated:   # 72-ch, pad 2 dilate 2 (:514-515)
+                    off = _conv(P, oname, y, pad=2, dilate=2, bias=True)
+                else:                # 18-ch, pad 1 (:1232-1234)
+                    off = _conv(P, oname, y, pad=1, bias=True)
+                y = O.deform_conv2d(y, off, P[p + "res" + u + "_branch2b_weight"],
+                                    stride=1, pad=2, dilate=2, dg=dcn_dg)
+            else:
+                y = _conv(P, p + "res" + u + "_branch2b", y, pad=1)
+            y = O.relu(_bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN))
+            y = _bn(P, p + "bn" + u + "_branch2c", _conv(P, p + "res" + u + "_branch2c", y), EPS_DCN)
+            x = O.relu(sc + y)
+    return x
+
+
+def _namer101(stage, n):
+    if stage in (3, 4):
+        return ["a"] + ["b%d" % i for i in range(1, n)]
+    return [chr(ord("a") + i) for i in range(n)]
+
+
+def _namer50(stage, n):
+    return [chr(ord("a") + i) for i in range(n)]
+
+
+def resnet_dcn_101(P, data):
+    return resnet_dcn_bottleneck(P, data, (3, 4, 23, 3), "", _namer101, 1, False)
+
+
+def resnet_dcn_50(P, data):
+    return resnet_dcn_bottleneck(P, data, (3, 4, 6, 3), "50_", _namer50, 4, True)
+
+
+# --------------------------------------------------------------------------
+# Pre-activation ResNet-18/34 trunk: resnet() :88-130 with residual_unit :71-86
+# --------------------------------------------------------------------------
+def resnet_preact_trunk(P, data, prefix, units):
+    p = prefix
+    x = _bn(P, p + "bn_data", data, EPS_PREACT, fix_gamma=True)
+    x = _conv(P, p + "conv0", x, stride=2, pad=3)
+    x = O.relu(_bn(P, p + "bn0", x, EPS_PREACT))
+    x = O.pool2d(x, "max", 3, 2, 1, "valid")
+    for i, n in enumerate(units):
+        for j in range(n):
+            name = "%sstage%d_unit%d" % (p, i + 1, j + 1)
+            stride = (1 if i == 0 else 2) if j == 0 else 1
+            act1 = O.relu(_bn(P, name + "_bn1", x, EPS_PREACT))
+            c1 = _conv(P, name + "_conv1", act1, stride=stride, pad=1)
+            act2 = O.relu(_bn(P, name + "_bn2", c1, EPS_PREACT))
+            c2 = _conv(P, name + "_conv2", act2, stride=1, pad=1)
+            if j == 0:   # dim_match=False on the first unit of EVERY stage (:122)
+                sc = _conv(P, name + "_sc", act1, stride=stride)
+            else:
+                sc = x
+            x = c2 + sc
+    return x
+
+
+def resnet_dcn_conv5_basic(P, feat, prefix, n_units):
+    """get_resnet_dcn_18_conv5 :132-170 (2 units) / get_resnet_dcn_34_conv5 :172-233 (3)."""
+    p = prefix
+    x = feat
+    for ui in range(n_units):
+        u = "5" + chr(ord("a") + ui)
+        if ui == 0:
+            sc = _bn(P, p + "bn" + u + "_branch1", _conv(P, p + "res" + u + "_branch1", x, stride=2), EPS_DCN)
+            y = _conv(P, p + "res" + u + "_branch2a", x, stride=2, pad=1)
+        else:
+            sc = x
+            y = _conv(P, p + "res" + u + "_branch2a", x, stride=1, pad=1)
+        y = O.relu(_bn(P, p + "bn" + u + "_branch2a", y, EPS_DCN))
+        off = _conv(P, p + "res" + u + "_branch2b_offset", y, pad=2, dilate=2, bias=True)
+        y = O.deform_conv2d(y, off, P[p + "res" + u + "_branch2b_weight"], 1, 2, 2, dg=4)
+        y = _bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN)
+        x = O.relu(sc + y)
+    return x
+
+
+# --------------------------------------------------------------------------
+# FlowNet-S: get_flownet :1751-1808 (Convolution5_scale is dead on this path)
+# --------------------------------------------------------------------------
+def flownet(P, img_cur, img_ref):
+    lk = O.leaky_relu
+    data = np.concatenate([img_cur / np.float32(255.0), img_ref / np.float32(255.0)], axis=1)
+    x = O.pool2d(data, "avg", 2, 2, 0, "full")
+    r1 = lk(_conv(P, "flow_conv1", x, 2, 3, bias=True))
+    r2 = lk(_conv(P, "conv2", r1, 2, 2, bias=True))
+    r3 = lk(_conv(P, "conv3", r2, 2, 2, bias=True))
+    r4 = lk(_conv(P, "conv3_1", r3, 1, 1, bias=True))
+    r5 = lk(_conv(P, "conv4", r4, 2, 1, bias=True))
+    r6 = lk(_conv(P, "conv4_1", r5, 1, 1, bias=True))
+    r7 = lk(_conv(P, "conv5", r6, 2, 1, bias=True))
+    r8 = lk(_conv(P, "conv5_1", r7, 1, 1, bias=True))
+    r9 = lk(_conv(P, "conv6", r8, 2, 1, bias=True))
+    r10 = lk(_conv(P, "conv6_1", r9, 1, 1, bias=True))
+
+    def refine(feat_in, skip, pred_name, deconv_name, upflow_name):
+        pred = _conv(P, pred_name, feat_in, 1, 1, bias=True)
+        dec = O.deconv2d(feat_in, P[deconv_name + "_weight"], P[deconv_name + "_bias"], 2, 0)
+        dec = lk(O.crop_like(dec, skip.shape[2:], (1, 1)))
+        up = O.deconv2d(pred, P[upflow_name + "_weight"], P[upflow_name + "_bias"], 2, 0)
+        up = O.crop_like(up, skip.shape[2:], (1, 1))
+        return np.concatenate([skip, dec, up], axis=1)
+
+    c2 = refine(r10, r8, "Convolution1", "deconv5", "upsample_flow6to5")
+    c3 = refine(c2, r6, "Convolution2", "deconv4", "upsample_flow5to4")
+    c4 = refine(c3, r4, "Convolution3", "deconv3", "upsample_flow4to3")
+    c5 = refine(c4, r2, "Convolution4", "deconv2", "upsample_flow3to2")
+    c5 = O.pool2d(c5, "avg", 2, 2, 0, "full")
+    flow = _conv(P, "Convolution5", c5, 1, 1, bias=True)
+    return flow * np.float32(2.5)
+
+
+# --------------------------------------------------------------------------
+# task head: fc6 -> relu -> score -> Deconvolution 32x32 s16 g19 -> Crop(8,8)
+# accel_18.py:136-155,178-197,208-227
+# --------------------------------------------------------------------------
+def head(P, feat, data_hw, prefix=""):
+    p = prefix
+    x = O.relu(_conv(P, p + "fc6", feat, bias=True))
+    s = _conv(P, p + "score", x, bias=True)
+    ncls = s.shape[1]
+    up = O.deconv2d(s, P[p + "upsampling_weight"], None, 16, 0, groups=ncls)
+    return O.crop_like(up, data_hw, (8, 8))
+
+
+def key_forward(P, data):
+    """get_key_test_symbol (accel_18.py:121-159; identical in 34/50/101).
+    returns {'res5c_relu_output', 'croped_score_output'}."""
+    feat = resnet_dcn_101(P, data)
+    score = head(P, feat, data.shape[2:])
+    return {"res5c_relu_output": feat, "croped_score_output": score}
+
+
+def cur_forward(P, version, data, data_key, feat_key):
+    """get_cur_test_symbol: accel_18.py:161-239, accel_34.py:161-239,
+    accel_50.py:156-228, accel_101.py:144-193."""
+    version = str(version)
+    flow = flownet(P, data, data_key)
+    warped = O.flow_warp(feat_key, flow)
+    out = {"warping_feat_output": warped, "_flow": flow}
+    hw = data.shape[2:]
+    if version == "101":
+        cur = resnet_dcn_101(P, data)
+        fused = O.conv2d(np.concatenate([warped, cur], axis=1), P["corr_weight"], P["corr_bias"])
+        out["croped_score_output"] = head(P, fused, hw)
+        return out
+    left = head(P, warped, hw)
+    if version in ("18", "34"):
+        p = version + "_"
+        units = [2, 2, 2] if version == "18" else [3, 4, 6]
+        r = resnet_preact_trunk(P, data, p, units)
+        r = resnet_dcn_conv5_basic(P, r, p, 2 if version == "18" else 3)
+        r = O.deconv2d(r, P[p + "feat_upsampling_weight"], None, 2, 1)
+        right = head(P, r, hw, p)
+    elif version == "50":
+        r = resnet_dcn_50(P, data)
+        right = head(P, r, hw, "curr_")
+    else:
+        raise ValueError(version)
+    out["correction_output"] = O.conv2d(np.concatenate([left, right], axis=1),
+                                        P["corr_weight"], P["corr_bias"])
+    return out
+
+
+def run_clip(P, version, frames, interval):
+    """The demo.py:228-250 schedule on preprocessed frames (list of 1x3xHxW):
+    idx % interval == 0 -> key graph, else cur graph with data_key = PREVIOUS
+    frame and feat_key = previously propagated feature (demo.py:176-181,241).
+    Returns per-frame (logits, labels)."""
+    version = str(version)
+    outs = []
+    feat = None
+    prev = None
+    for idx, im in enumerate(frames):
+        if prev is None:
+            prev = im
+        if idx % interval == 0:
+            o = key_forward(P, im)
+            feat = o["res5c_relu_output"]
+            logits = o["croped_score_output"]
+        else:
+            o = cur_forward(P, version, im, prev, feat)
+            feat = o["warping_feat_output"]
+            logits = o["croped_score_output" if version == "101" else "correction_output"]
+        prev = im
+        outs.append((logits, O.argmax_c(logits)))
+    return outs

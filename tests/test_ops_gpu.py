@@ -1,0 +1,182 @@
+"""Operator-level parity: HIP kernels (through the C ABI) vs the CPU oracle on
+the same seeded inputs.  fp32; tolerance 1e-4 relative to the output scale per
+op (the end-to-end logit tolerance of BASELINE.json is 1e-3)."""
+import numpy as np
+import pytest
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def close(a, b, rtol=1e-4):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    tol = rtol * max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol, "max err %g > tol %g" % (err, tol)
+
+
+CONV_CASES = [
+    # C, K, H, W, k, s, p, d
+    (64, 64, 24, 40, 1, 1, 0, 1),
+    (64, 128, 24, 40, 3, 1, 1, 1),
+    (128, 64, 25, 41, 3, 2, 1, 1),       # odd sizes, stride 2
+    (32, 72, 16, 24, 3, 1, 2, 2),        # dilated offset conv, 72 channels
+    (256, 18, 16, 24, 3, 1, 1, 1),       # 18-channel offset conv
+    (3, 64, 64, 96, 7, 2, 3, 1),         # RGB stem
+    (6, 64, 64, 96, 7, 2, 3, 1),         # FlowNet stem
+    (64, 128, 32, 48, 5, 2, 2, 1),       # FlowNet conv2
+    (1026, 2, 8, 16, 3, 1, 1, 1),        # flow predictor on a concat with ragged channel count
+    (194, 2, 16, 32, 3, 1, 1, 1),
+    (256, 512, 17, 23, 1, 2, 0, 1),      # 1x1 stride-2 shortcut
+    (2048, 19, 8, 16, 1, 1, 0, 1),       # score conv
+    (8, 8, 1, 1, 3, 1, 1, 1),            # degenerate 1x1 image
+]
+
+
+@pytest.mark.parametrize("C,K,H,W,k,s,p,d", CONV_CASES)
+def test_conv2d_bias(ctx, C, K, H, W, k, s, p, d):
+    x, w, b = rnd(1, 1, C, H, W), rnd(2, K, C, k, k, scale=(2.0 / (C * k * k)) ** 0.5), rnd(3, K)
+    close(ctx.conv2d(x, w, b, s, p, d), O.conv2d(x, w, b, s, p, d))
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_conv2d_every_tile_config(ctx, tile):
+    C, K, H, W = 96, 200, 20, 36
+    x, w = rnd(4, 1, C, H, W), rnd(5, K, C, 3, 3, scale=0.05)
+    close(ctx.conv2d(x, w, None, 1, 1, 1, tile=tile), O.conv2d(x, w, None, 1, 1, 1))
+
+
+def test_conv2d_fused_epilogue(ctx):
+    C, K, H, W = 64, 96, 20, 28
+    x, w = rnd(6, 1, C, H, W), rnd(7, K, C, 3, 3, scale=0.05)
+    scale, shift, res = rnd(8, K), rnd(9, K), rnd(10, 1, K, H, W)
+    ref = O.conv2d(x, w, None, 1, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=1), O.relu(ref))
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=2, slope=0.1),
+          O.leaky_relu(ref, 0.1))
+
+
+def test_conv2d_identity_detects_transpose(ctx):
+    # A = I with an asymmetric B: a row/col swap in the MFMA C-layout cannot pass
+    C = 64
+    x = rnd(11, 1, C, 8, 8)
+    w = np.zeros((C, C, 1, 1), np.float32)
+    w[np.arange(C), (np.arange(C) * 7 + 3) % C, 0, 0] = np.arange(1, C + 1, dtype=np.float32)
+    close(ctx.conv2d(x, w), O.conv2d(x, w))
+
+
+@pytest.mark.parametrize("C,K,H,W,bias", [(64, 32, 9, 13, True), (1026, 512, 4, 6, True), (2, 2, 8, 16, True),
+                                           (512, 256, 8, 8, False)])
+def test_deconv_4x4_s2(ctx, C, K, H, W, bias):
+    x, w = rnd(12, 1, C, H, W), rnd(13, C, K, 4, 4, scale=(0.5 / C) ** 0.5)
+    b = rnd(14, K) if bias else None
+    # pad 1 directly ...
+    ref = O.deconv2d(x, w, b, 2, 1)
+    close(ctx.deconv2d_4x4s2(x, w, b), ref)
+    # ... equals the reference's pad 0 + Crop(offset=(1,1)) form (resnet_v1_101_flownet_deeplab.py:1775-1777)
+    ref0 = O.crop_like(O.deconv2d(x, w, b, 2, 0), (2 * H, 2 * W), (1, 1))
+    np.testing.assert_array_equal(ref, ref0)
+    close(ctx.deconv2d_4x4s2(x, w, b, act=2, slope=0.1), O.leaky_relu(ref, 0.1))
+
+
+def _offsets(seed, dg, H, W, kind):
+    r = np.random.default_rng(seed)
+    shp = (1, 18 * dg, H, W)
+    if kind == "zero":
+        return np.zeros(shp, np.float32)
+    if kind == "integer":
+        return r.integers(-2, 3, shp).astype(np.float32)
+    if kind == "fractional":
+        return r.normal(0, 1.0, shp).astype(np.float32)
+    return r.normal(0, 12.0, shp).astype(np.float32)   # border-crossing stress
+
+
+@pytest.mark.parametrize("dg", [1, 4])
+@pytest.mark.parametrize("kind", ["zero", "integer", "fractional", "border"])
+def test_deform_conv(ctx, dg, kind):
+    C, K, H, W = 32, 48, 12, 20
+    x, w = rnd(15, 1, C, H, W), rnd(16, K, C, 3, 3, scale=0.06)
+    off = _offsets(17, dg, H, W, kind)
+    ref = O.deform_conv2d(x, off, w, 1, 2, 2, dg)
+    close(ctx.deform_conv2d(x, off, w, 1, 2, 2, dg), ref)
+    if kind == "zero":   # zero offsets == plain dilated convolution
+        close(ref, O.conv2d(x, w, None, 1, 2, 2), rtol=1e-5)
+
+
+@pytest.mark.parametrize("H,W", [(32, 48), (33, 47), (7, 9)])
+@pytest.mark.parametrize("kind,k,s,p,conv", [("max", 3, 2, 0, "full"), ("max", 3, 2, 1, "valid"), ("avg", 2, 2, 0, "full")])
+def test_pool(ctx, H, W, kind, k, s, p, conv):
+    x = rnd(18, 1, 20, H, W)
+    got, ref = ctx.pool2d(x, kind, k, s, p, conv), O.pool2d(x, kind, k, s, p, conv)
+    if kind == "max":
+        np.testing.assert_array_equal(got, ref)
+    else:
+        close(got, ref, 1e-6)
+
+
+def test_pool_bn_relu_epilogue(ctx):
+    x, scale, shift = rnd(19, 1, 64, 16, 24), rnd(20, 64), rnd(21, 64)
+    ref = O.relu(O.pool2d(x, "max", 3, 2, 1, "valid") * scale[None, :, None, None] + shift[None, :, None, None])
+    close(ctx.pool2d(x, "max", 3, 2, 1, "valid", scale=scale, shift=shift, relu=True), ref, 1e-6)
+
+
+@pytest.mark.parametrize("mag", [0.0, 0.7, 3.0, 40.0])
+def test_flow_warp(ctx, mag):
+    C, H, W = 64, 12, 20
+    feat, flow = rnd(22, 1, C, H, W), rnd(23, 1, 2, H, W, scale=mag)
+    close(ctx.flow_warp(feat, flow), O.flow_warp(feat, flow), 1e-5)
+    if mag == 0.0:
+        close(O.flow_warp(feat, flow), feat, 1e-5)
+
+
+def test_flow_input(ctx):
+    cur, prev = rnd(24, 1, 3, 32, 64, scale=60), rnd(25, 1, 3, 32, 64, scale=60)
+    data = np.concatenate([cur / np.float32(255.0), prev / np.float32(255.0)], axis=1)
+    close(ctx.flow_input(cur, prev), O.pool2d(data, "avg", 2, 2, 0, "full"), 1e-6)
+
+
+def _tail_ref(left, wl, right=None, wr=None, cw=None, cb=None):
+    n = left.shape[1]
+    H, W = left.shape[2] * 16, left.shape[3] * 16
+    a = O.crop_like(O.deconv2d(left, wl, None, 16, 0, groups=n), (H, W), (8, 8))
+    if right is None:
+        return a
+    b = O.crop_like(O.deconv2d(right, wr, None, 16, 0, groups=n), (H, W), (8, 8))
+    return O.conv2d(np.concatenate([a, b], axis=1), cw, cb)
+
+
+@pytest.mark.parametrize("bilinear", [True, False])
+@pytest.mark.parametrize("two", [False, True])
+def test_score_fuse(ctx, bilinear, two):
+    from accel_amd.utils.synth import bilinear_kernel
+    n, Hs, Ws = 19, 4, 6
+    left, right = rnd(26, 1, n, Hs, Ws, scale=3), rnd(27, 1, n, Hs, Ws, scale=3)
+    wl = bilinear_kernel(n, 32) if bilinear else rnd(28, n, 1, 32, 32, scale=0.2)
+    wr = bilinear_kernel(n, 32) if bilinear else rnd(29, n, 1, 32, 32, scale=0.2)
+    cw, cb = rnd(30, n, 2 * n, 1, 1, scale=0.3), rnd(31, n)
+    if two:
+        logits, labels = ctx.score_fuse(left, wl, right, wr, cw, cb)
+        ref = _tail_ref(left, wl, right, wr, cw, cb)
+    else:
+        logits, labels = ctx.score_fuse(left, wl)
+        ref = _tail_ref(left, wl)
+    close(logits, ref, 1e-5)
+    np.testing.assert_array_equal(labels, O.argmax_c(logits))   # fused argmax == argmax of its own logits
+    srt = np.sort(ref, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-3
+    np.testing.assert_array_equal(labels[safe], O.argmax_c(ref)[safe])
+
+
+def test_argmax_ties_pick_first(ctx):
+    x = np.zeros((1, 19, 4, 8), np.float32)
+    x[0, 5] = 1.0
+    x[0, 9] = 1.0          # exact tie -> first index (5)
+    x[0, 3, 0, 0] = 2.0
+    got = ctx.argmax_c(x)
+    np.testing.assert_array_equal(got, O.argmax_c(x))
+    assert got[0, 0, 0] == 3 and got[0, 1, 1] == 5
