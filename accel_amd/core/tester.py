@@ -1,0 +1,173 @@
+"""Predictor / im_segment with the reference's signatures
+(dff_deeplab/core/tester.py:22-35,158-171), running lowered plans on the HIP
+executor instead of an MXNet MutableModule.
+
+Contract kept from the reference:
+  * Predictor(symbol, data_names, label_names, context, max_data_shapes,
+    provide_data, provide_label, arg_params, aux_params): bind + init_params;
+    missing / mis-shaped parameters raise at construction (allow_missing=False).
+  * predict(data_batch) -> [ {output_name: array} ] (one dict per device);
+    inputs are copied into executor-owned buffers, outputs stay valid until the
+    next forward; arrays are device handles whose .asnumpy() synchronises.
+  * a key predictor and a cur predictor built on the same context share the
+    propagated feature in HBM: feeding `feat` back as `feat_key`
+    (demo.py:241-243) costs nothing when it is the handle the previous predict
+    returned; a host array is uploaded instead.
+Shapes are static per bind; a new (H, W) re-lowers and re-binds like
+MutableModule.forward does on a shape change (module.py:1026-1042).
+"""
+import numpy as np
+
+from .. import lower as _lower
+from .. import runtime
+from ..mx.ndarray import DeviceArray
+
+_MODELS = {}   # device id -> shared runtime.Model (key + cur plans of one demo share it)
+
+
+def _device_id(context):
+    ctx = context[0] if isinstance(context, (list, tuple)) else context
+    return int(getattr(ctx, "device_id", 0) or 0)
+
+
+def shared_model(device_id):
+    if device_id not in _MODELS:
+        _MODELS[device_id] = runtime.Model(runtime.Context(device_id))
+    return _MODELS[device_id]
+
+
+def release_models():
+    for m in _MODELS.values():
+        m.close()
+        m.ctx.close()
+    _MODELS.clear()
+
+
+class Predictor(object):
+    def __init__(self, symbol, data_names, label_names, context=None, max_data_shapes=None,
+                 provide_data=None, provide_label=None, arg_params=None, aux_params=None, model=None):
+        self._symbol = symbol
+        self._data_names = list(data_names)
+        self.output_names = symbol.list_outputs()
+        self._model = model if model is not None else shared_model(_device_id(context))
+        self._arg_params = arg_params or {}
+        self._aux_params = aux_params or {}
+        self._params_loaded = False
+        self._plans = {}      # (H, W) -> (role, runtime.Plan, Lowering)
+        self._is_key = "feat_key" in self.output_names or any(n.startswith("res5c_relu") for n in self.output_names)
+        shapes = dict(provide_data[0]) if provide_data else {}
+        if max_data_shapes:
+            for k, v in max_data_shapes[0]:
+                shapes.setdefault(k, v)
+        if "data" in shapes:
+            self._bind(tuple(shapes["data"])[2:])
+
+    # -- bind = lower + finalize --------------------------------------------------------------
+    def _check_params(self, lw_sym, input_shapes):
+        arg_shapes, _, aux_shapes = lw_sym.infer_shape(**input_shapes)
+        for name, shp in zip(lw_sym.list_arguments(), arg_shapes):
+            if name in input_shapes:
+                continue
+            if name not in self._arg_params:
+                raise RuntimeError("%s not initialized" % name)
+            got = tuple(self._arg_params[name].shape)
+            if got != tuple(shp):
+                raise RuntimeError("shape inconsistent for %s inferred %s provided %s" % (name, shp, got))
+        for name, shp in zip(lw_sym.list_auxiliary_states(), aux_shapes):
+            if name not in self._aux_params:
+                raise RuntimeError("%s not initialized" % name)
+            got = tuple(self._aux_params[name].shape)
+            if got != tuple(shp):
+                raise RuntimeError("shape inconsistent for %s inferred %s provided %s" % (name, shp, got))
+
+    def _bind(self, hw):
+        H, W = int(hw[0]), int(hw[1])
+        if (H, W) in self._plans:
+            return self._plans[(H, W)]
+        if H % 128 or W % 128:
+            raise ValueError("image size %dx%d: the FlowNet encoder/decoder needs multiples of 128" % (H, W))
+        feat_shape = (1, 2048, 1, 1) if self._is_key else (1, 2048, H // 16, W // 16)
+        shapes = {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": feat_shape}
+        self._check_params(self._symbol, shapes)
+        if not self._params_loaded:
+            self._model.set_params(self._arg_params, self._aux_params)
+            self._params_loaded = True
+        text, lw = _lower.lower(self._symbol, shapes)
+        role = "%s_%dx%d_%x" % ("key" if self._is_key else "cur", H, W, id(self) & 0xFFFF)
+        plan = self._model.add_plan(role, text)
+        plan.finalize()
+        self._plans[(H, W)] = (plan, lw)
+        return self._plans[(H, W)]
+
+    # -- forward ---------------------------------------------------------------------------------
+    def predict(self, data_batch):
+        arrays = dict(zip(self._data_names, data_batch.data[0]))
+        data = arrays["data"]
+        H, W = tuple(data.shape)[2:]
+        plan, lw = self._bind((H, W))
+        m = self._model
+        m.write("data", _host(arrays["data"]))
+        if not self._is_key:
+            m.write("data_key", _host(arrays["data_key"]))
+            fk = arrays["feat_key"]
+            ref = getattr(fk, "device_ref", None)
+            if not (ref and ref[0] is m and ref[1] == "feat"):
+                self._upload_feat(_host(fk), H, W)
+        plan.run()
+        out = {}
+        for name in self.output_names:
+            d = lw.outputs.get(name)
+            if isinstance(d, str) and d.startswith("input:"):
+                out[name] = arrays[d[6:]]
+            elif d == "logits":
+                out[name] = self._logits_handle(H, W)
+            else:
+                out[name] = self._feat_handle(H, W)
+        return [out]
+
+    def _logits_handle(self, H, W, ncls=19):
+        m = self._model
+
+        def labels():
+            # mx.ndarray.argmax returns float indices; the fused kernel wrote uint8 labels
+            return DeviceArray(shape=(1, H, W), fetch=lambda: m.read("labels", (1, H, W), np.uint8).astype(np.float32),
+                               device_ref=(m, "labels"))
+        return DeviceArray(shape=(1, ncls, H, W), fetch=lambda: m.read("logits", (1, ncls, H, W)),
+                           device_ref=(m, "logits"), labels_of=labels)
+
+    def _feat_handle(self, H, W):
+        m = self._model
+        h, w = H // 16, W // 16
+
+        def fetch():
+            nhwc = m.read("feat", (h, w, 2048))
+            return np.ascontiguousarray(nhwc.transpose(2, 0, 1))[None]
+        return DeviceArray(shape=(1, 2048, h, w), fetch=fetch, device_ref=(m, "feat"))
+
+    def _upload_feat(self, feat_nchw, H, W):
+        f = np.asarray(feat_nchw, np.float32)
+        if f.shape != (1, 2048, H // 16, W // 16):
+            raise ValueError("feat_key shape %s does not match the bound graph" % (f.shape,))
+        self._model.write("feat", np.ascontiguousarray(f[0].transpose(1, 2, 0)))
+
+    def plan_for(self, H, W):
+        return self._bind((H, W))
+
+
+def _host(a):
+    if hasattr(a, "asnumpy"):
+        a = a.asnumpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def im_segment(predictor, data_batch):
+    """tester.py:158-171: returns (output_all, feat) where feat is the feature to
+    propagate: res5c_relu_output after a key frame, warping_feat_output otherwise."""
+    output_all = predictor.predict(data_batch)
+    if 'res5c_relu_output' in output_all[0]:
+        feat = output_all[0]['res5c_relu_output']
+    elif 'warping_feat_output' in output_all[0]:
+        feat = output_all[0]['warping_feat_output']
+    else:
+        feat = None
+    return output_all, feat

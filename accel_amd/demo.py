@@ -1,0 +1,215 @@
+"""Accel inference + mIoU + timing harness: the counterpart of
+dff_deeplab/demo.py (the only working segmentation harness of the reference,
+SURVEY.md F2), on the HIP runtime.
+
+    python -m accel_amd.demo --version 18 --interval 5 --num_ex 10 [--avg]
+                             [--data DIR --labels DIR | --synthetic HxW]
+                             [--params accel-18-0000.params flownet-0000.params]
+
+Reproduced behaviour (demo.py:107-284): frame selection (`lb_pos = 19`,
+`offset = interval-1` or `i % interval` with --avg), key/non-key schedule
+(`idx % interval == 0`), `data_key` = PREVIOUS frame, feature feedback,
+`correction_output` vs `croped_score_output` (Accel-101), 2 warm-up frames,
+tic/toc around forward + argmax + label-map fetch, fast_hist/per_class_iu mIoU.
+Without Cityscapes on disk the clip source is synthetic (`--synthetic`).
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+
+from . import mx
+from .config.config import config, update_config
+from .core.tester import Predictor, im_segment
+from .utils.image import resize, transform
+from .utils.tictoc import tic, toc
+
+
+def fast_hist(pred, label, n):
+    """demo.py:50-53"""
+    k = (label >= 0) & (label < n)
+    return np.bincount(n * label[k].astype(int) + pred[k], minlength=n ** 2).reshape(n, n)
+
+
+def per_class_iu(hist):
+    """demo.py:55-56"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+
+
+def select_frames(image_names, num_ex, interv, avg_acc, snip_len=30, lb_pos=19):
+    """demo.py:152-163: per 30-frame snippet keep `interv` frames positioned so
+    that the labelled frame (index 19) is `offset` frames after the key frame."""
+    out = []
+    for i in range(num_ex):
+        snip_pos = i * snip_len
+        offset = i % interv if avg_acc else interv - 1
+        start_pos = lb_pos - offset
+        out.extend(image_names[snip_pos + start_pos: snip_pos + start_pos + interv])
+    return out
+
+
+def get_symbols(version, cfg):
+    from . import symbols
+    name = "accel_" + str(version)
+    inst = getattr(getattr(symbols, name), name)()
+    return inst, inst.get_key_test_symbol(cfg), inst.get_cur_test_symbol(cfg)
+
+
+def build_batches(frames_bgr, cfg):
+    """demo.py:165-190: list of [data, data_key, feat_key] arrays per frame."""
+    data, prev = [], None
+    for im in frames_bgr:
+        target_size, max_size = cfg.SCALES[0][0], cfg.SCALES[0][1]
+        im, _ = resize(im, target_size, max_size, stride=cfg.network.IMAGE_STRIDE)
+        im_tensor = transform(im, cfg.network.PIXEL_MEANS)
+        if prev is None:
+            prev = im_tensor
+        data.append([mx.nd.array(im_tensor), mx.nd.array(prev),
+                     mx.nd.array(np.zeros((1, cfg.network.DFF_FEAT_DIM, 1, 1)))])
+        prev = im_tensor
+    return data
+
+
+class ClipRunner(object):
+    """The demo.py hot loop as an object: a key and a cur Predictor sharing one device."""
+
+    data_names = ['data', 'data_key', 'feat_key']
+
+    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None):
+        self.version = str(version)
+        self.cfg = cfg
+        H, W = frame_hw
+        _, key_sym, cur_sym = get_symbols(version, cfg)
+        ctx = context or [mx.gpu(0)]
+        max_shape = [[('data', (1, 3, H, W)), ('data_key', (1, 3, H, W))]]
+        provide = [[('data', (1, 3, H, W)), ('data_key', (1, 3, H, W)), ('feat_key', (1, 2048, 1, 1))]]
+        self.key_predictor = Predictor(key_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
+                                       provide_data=provide, provide_label=[None],
+                                       arg_params=arg_params, aux_params=aux_params)
+        self.cur_predictor = Predictor(cur_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
+                                       provide_data=provide, provide_label=[None],
+                                       arg_params=arg_params, aux_params=aux_params)
+        self.feat = None
+        self.output_key = 'croped_score_output' if self.version == '101' else 'correction_output'
+
+    def step(self, idx, arrays, interval):
+        """One frame (demo.py:235-245).  Returns (logits handle, label-map handle)."""
+        batch = mx.io.DataBatch(data=[list(arrays)], label=[], pad=0, index=idx,
+                                provide_data=[[(k, v.shape) for k, v in zip(self.data_names, arrays)]],
+                                provide_label=[None])
+        if idx % interval == 0:
+            output_all, self.feat = im_segment(self.key_predictor, batch)
+            logits = output_all[0]['croped_score_output']
+        else:
+            batch.data[0][-1] = self.feat
+            batch.provide_data[0][-1] = ('feat_key', self.feat.shape)
+            output_all, self.feat = im_segment(self.cur_predictor, batch)
+            logits = output_all[0][self.output_key]
+        return logits, mx.nd.argmax(logits, axis=1)
+
+
+def run_clip(version, cfg, arg_params, aux_params, frames_bgr, interval, want_logits=True):
+    """Runs the demo schedule over `frames_bgr`; returns per-frame (logits, labels) numpy."""
+    data = build_batches(frames_bgr, cfg)
+    H, W = data[0][0].shape[2:]
+    runner = ClipRunner(version, cfg, arg_params, aux_params, (H, W))
+    outs = []
+    for idx, arrays in enumerate(data):
+        logits, labels = runner.step(idx, arrays, interval)
+        lab = np.uint8(np.squeeze(labels.asnumpy()))
+        outs.append((logits.asnumpy() if want_logits else None, lab))
+    return outs
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='Accel demo (MI355X)')
+    ap.add_argument('--version', default='18')
+    ap.add_argument('--interval', type=int, default=5)
+    ap.add_argument('--num_ex', type=int, default=10)
+    ap.add_argument('--avg', dest='avg_acc', action='store_true')
+    ap.add_argument('--cfg', default=None, help='experiments/dff_deeplab/cfgs/dff_deeplab_vid_demo.yaml')
+    ap.add_argument('--data', default='', help='Cityscapes root (leftImg8bit_sequence/, gtFine/)')
+    ap.add_argument('--synthetic', default='1024x2048')
+    ap.add_argument('--params', nargs='*', default=[], help='MXNet .params checkpoints, merged in order')
+    args = ap.parse_args(argv)
+    version, interv, num_ex = str(args.version), args.interval, args.num_ex
+    if version not in ['18', '34', '50', '101']:
+        raise ValueError("Invalid Accel version '%s' - must be one of Accel-{18,34,50,101}" % version)
+    if interv < 1:
+        raise ValueError("Invalid interval %d - must be >=1" % interv)
+    if num_ex < 1:
+        raise ValueError("Invalid num_ex %d - must be >=1" % num_ex)
+    if args.cfg:
+        update_config(args.cfg)
+    num_classes = config.dataset.NUM_CLASSES
+
+    labels = {}
+    if args.data:
+        from PIL import Image
+        names, label_files = [], []
+        for city in ('frankfurt', 'lindau', 'munster'):
+            names += sorted(glob.glob(os.path.join(args.data, 'leftImg8bit_sequence/val', city, '*.png')))
+            label_files += sorted(glob.glob(os.path.join(args.data, 'gtFine/val', city, '*trainIds.png')))
+        names = select_frames(names[:30 * num_ex], num_ex, interv, args.avg_acc)
+        frames = [np.asarray(Image.open(n).convert('RGB'))[:, :, ::-1] for n in names]
+        for lf in label_files:
+            c = os.path.basename(lf).split('_')
+            labels[(c[1], c[2])] = lf
+    else:
+        from .utils import synth
+        H, W = [int(v) for v in args.synthetic.split('x')]
+        config.SCALES[0] = (H, W)
+        frames, names = [], []
+        for i in range(num_ex):
+            clip = synth.make_clip(H, W, interv, seed=20260929 + i)
+            frames += clip
+            names += ['synthetic_%06d_%06d_leftImg8bit.png' % (i, t) for t in range(interv)]
+
+    from .utils import load_model, synth
+    H, W = frames[0].shape[:2]
+    if args.params:
+        arg_params, aux_params = {}, {}
+        for prefix in args.params:
+            a, x = load_model.load_param_file(prefix, process=True)
+            arg_params.update(a)
+            aux_params.update(x)
+    else:
+        print('no --params given: seeded random weights (throughput is valid, mIoU is meaningless)')
+        arg_params, aux_params = synth.model_params(version, H, W, config)
+
+    data = build_batches(frames, config)
+    runner = ClipRunner(version, config, arg_params, aux_params, (H, W))
+    for j in range(min(2, len(data))):       # warm up (demo.py:207-220)
+        runner.step(j, data[j], interv)[1].asnumpy()
+    print("warmup done")
+    time_sum, count = 0.0, 0
+    hist = np.zeros((num_classes, num_classes))
+    for idx, arrays in enumerate(data):
+        tic()
+        _, lab = runner.step(idx, arrays, interv)
+        pred = np.uint8(np.squeeze(lab.asnumpy()))
+        elapsed = toc()
+        time_sum += elapsed
+        count += 1
+        print('testing {} {:.4f}s [{:.4f}s]'.format(names[idx], elapsed, time_sum / count))
+        comps = os.path.basename(names[idx]).split('_')
+        lf = labels.get((comps[1], comps[2])) if len(comps) > 2 else None
+        if lf is not None:
+            from PIL import Image
+            label = np.asarray(Image.open(lf))
+            curr_hist = fast_hist(pred.flatten(), label.flatten(), num_classes)
+            hist += curr_hist
+            print('mIoU {mIoU:.3f}'.format(mIoU=round(np.nanmean(per_class_iu(curr_hist)) * 100, 2)))
+            print('(cum) mIoU {mIoU:.3f}'.format(mIoU=round(np.nanmean(per_class_iu(hist)) * 100, 2)))
+    if hist.sum() > 0:
+        ious = per_class_iu(hist) * 100
+        print(' '.join('{:.03f}'.format(i) for i in ious))
+        print('===> final mIoU {mIoU:.3f}'.format(mIoU=round(np.nanmean(ious), 2)))
+    print('{:.2f} frames/s'.format(count / time_sum))
+    print('done')
+
+
+if __name__ == '__main__':
+    main()
