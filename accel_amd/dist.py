@@ -1,0 +1,106 @@
+"""Multi-GPU side of the Accel path: one process per GPU, clips (key-frame
+groups) sharded statically across ranks, and an RCCL gather of per-frame
+logits to rank 0 -- the only collective on the path.
+
+A clip is the unit of independence: frame t of a clip needs frame t-1's image
+and propagated feature (demo.py:176-181,241-243), every key frame resets the
+chain.  So ranks never exchange activations; weights are replicated.
+
+The reference's own multi-GPU inference does the same thing with one Python
+thread per GPU and host-side merging (dff_rfcn/function/test_rcnn.py:62-82).
+"""
+import os
+
+import numpy as np
+
+
+def shard_clips(num_clips, world_size, rank):
+    """Contiguous static partition (config 4: 64 clips -> 8 per GPU)."""
+    per = (num_clips + world_size - 1) // world_size
+    lo = min(rank * per, num_clips)
+    return list(range(lo, min(lo + per, num_clips)))
+
+
+def assign_videos_greedy(frame_counts, world_size):
+    """test_rcnn.py:62-68: each video goes to the device with the fewest frames so far."""
+    loads = [0] * world_size
+    owner = []
+    for n in frame_counts:
+        r = int(np.argmin(loads))
+        owner.append(r)
+        loads[r] += n
+    return owner, loads
+
+
+def env_rank():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+class _DevPtr(object):
+    """Zero-copy torch view of an HBM buffer owned by libaccel_hip."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def as_torch(ptr, shape, dtype="f4", device=0):
+    import torch
+    return torch.as_tensor(_DevPtr(ptr, shape, {"f4": "<f4", "u1": "|u1"}[dtype]), device="cuda:%d" % device)
+
+
+class FrameGather(object):
+    """Asynchronous gather of each frame's output (logits fp32 19xHxW, or the
+    uint8 label map) to rank 0, overlapped with the next frame's compute.
+
+    Per frame: D2D copy of the model's output buffer into one of two staging
+    tensors on the compute stream (so the next frame may overwrite the output),
+    then `dist.gather(async_op=True)` issued with the compute stream current --
+    RCCL's stream waits for the copy and runs beside the next frame.  Each peer
+    uses its own direct xGMI link to the root, so the 7 sends of a step run
+    concurrently; no ring, no all-reduce."""
+
+    def __init__(self, model, ctx, what, shape, dtype, device, group=None, backend_device="cuda"):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.model, self.ctx, self.what = model, ctx, what
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group
+        tdt = {"f4": torch.float32, "u1": torch.uint8}[dtype]
+        dev = "cuda:%d" % device if backend_device == "cuda" else "cpu"
+        self.stage = [torch.empty(shape, dtype=tdt, device=dev) for _ in range(2)]
+        self.recv = [[torch.empty(shape, dtype=tdt, device=dev) for _ in range(self.world)] for _ in range(2)] \
+            if self.rank == 0 else [None, None]
+        self.work = [None, None]
+        self.n = 0
+        self.on_cuda = backend_device == "cuda"
+        self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev) if self.on_cuda else None
+        self.nbytes = int(np.prod(shape)) * (4 if dtype == "f4" else 1)
+
+    def submit(self):
+        s = self.n & 1
+        if self.work[s] is not None:
+            self.work[s].wait()
+        if self.on_cuda:
+            with self.torch.cuda.stream(self.stream):
+                self.model.read_device(self.what, self.stage[s].data_ptr(), self.nbytes)
+                self.work[s] = self.dist.gather(self.stage[s], self.recv[s], dst=0, group=self.group, async_op=True)
+        else:   # gloo / CPU path (tests)
+            self.stage[s].copy_(self.torch.from_numpy(self.model.read(self.what, tuple(self.stage[s].shape),
+                                                                      np.float32 if self.stage[s].dtype == self.torch.float32 else np.uint8)))
+            self.work[s] = self.dist.gather(self.stage[s], self.recv[s], dst=0, group=self.group, async_op=True)
+        self.n += 1
+        return s
+
+    def drain(self):
+        for s in (0, 1):
+            if self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None
+        if self.on_cuda:
+            self.stream.synchronize()
+
+    def last(self, slot):
+        """Root only: list (one per rank) of the tensors gathered in `slot`."""
+        return self.recv[slot]

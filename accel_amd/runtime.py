@@ -270,6 +270,10 @@ class Model(object):
         check(lib().accel_model_read(self.handle, buf.encode(), _fp(out), out.nbytes, 0))
         return out
 
+    def read_device(self, buf, dev_ptr, nbytes):
+        """enqueue a D2D copy of a persistent buffer into caller-owned HBM (no host sync)"""
+        check(lib().accel_model_read(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
+
     def buffer(self, buf):
         ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
         check(lib().accel_model_buffer(self.handle, buf.encode(), ctypes.byref(ptr), ctypes.byref(n)))

@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the Accel-18 inference path on 1024x2048
+clips at key-frame interval 5 (BASELINE.json metric, configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one clip per GPU = 1 key frame + 4 non-key frames through the HIP
+path (key: ResNet-101-DCN + head; non-key: FlowNet-S, flow warp, ResNet-18-DCN
+branch, two heads, fused upsample+correction+argmax).  Frames are synthetic,
+weights seeded random (no checkpoints/data offline); the clip is resident in
+HBM before the timed region; outputs (fp32 logits + uint8 labels) stay in HBM;
+with N > 1 every frame's logits are gathered to rank 0 over RCCL, overlapped.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+MFMA_F32_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+K80_ACCEL18_FPS = 1.0 / 0.44    # BASELINE.md section 1 (reference README.md:65): 0.44 s/frame on one Tesla K80
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--version", default="18")
+    ap.add_argument("--size", default="1024x2048")
+    ap.add_argument("--interval", type=int, default=5)
+    ap.add_argument("--gather", default="logits", choices=["logits", "labels", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(version, interval):
+    """The CPU oracle (a port: the reference's MXNet cannot run here)
+    timed on this box's host cores on a bounded sample."""
+    from accel_amd.config.config import config
+    from accel_amd.utils import image, synth
+    from oracle import graphs as G
+    h, w = 256, 512
+    arg, aux = synth.model_params(version, h, w, config)
+    P = dict(arg)
+    P.update(aux)
+    fr = [image.transform(f, config.network.PIXEL_MEANS).astype(np.float32) for f in synth.make_clip(h, w, 2)]
+    t0 = time.time()
+    k = G.key_forward(P, fr[0])
+    t1 = time.time()
+    G.cur_forward(P, version, fr[1], fr[0], k["res5c_relu_output"])
+    t2 = time.time()
+    scale = (1024 * 2048) / float(h * w)
+    per_frame = ((t1 - t0) + (interval - 1) * (t2 - t1)) / interval * scale
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count())),
+            "kind": "port",
+            "sample": "oracle/ (C restatement, OpenMP) on 1 key + 1 non-key frame of Accel-%s at %dx%d "
+                      "(1/%d of the pixels): key %.2f s, non-key %.2f s; kf=%d mean scaled x%d to 1024x2048"
+                      % (version, h, w, int(scale), t1 - t0, t2 - t1, interval, int(scale))}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, a.gpus))
+    H, W = [int(v) for v in a.size.split("x")]
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from accel_amd import demo, dist as adist, runtime
+    from accel_amd.config.config import config, update_config
+    from accel_amd.core import tester
+    from accel_amd.utils import image, synth
+    update_config(os.path.join(HERE, "tests", "golden", "dff_deeplab_vid_demo.yaml"))
+    config.SCALES[0] = (H, W)
+
+    arg, aux = synth.model_params(a.version, H, W, config)
+    model = runtime.Model(runtime.Context(local_rank))
+    tester._MODELS[local_rank] = model
+    runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)])
+    key_plan, _ = runner.key_predictor.plan_for(H, W)
+    cur_plan, _ = runner.cur_predictor.plan_for(H, W)
+    del arg, aux
+
+    # one clip per step, distinct per rank, resident in HBM
+    frames = synth.make_clip(H, W, a.interval, seed=20260929 + rank)
+    dev_frames = [torch.from_numpy(image.transform(f, config.network.PIXEL_MEANS).astype(np.float32)).cuda()
+                  for f in frames]
+    nbytes = 3 * H * W * 4
+
+    gather = None
+    gather_note = "none (single GPU)"
+    if world > 1 and a.gather != "none":
+        try:
+            if a.gather == "logits":
+                gather = adist.FrameGather(model, model.ctx, "logits", (19, H, W), "f4", local_rank)
+            else:
+                gather = adist.FrameGather(model, model.ctx, "labels", (H, W), "u1", local_rank)
+            gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered" % a.gather
+        except Exception as e:   # keep the bench alive; the JSON says what happened
+            gather, gather_note = None, "disabled: %r" % (e,)
+
+    def step():
+        for t in range(a.interval):
+            model.write_device("data", dev_frames[t].data_ptr(), nbytes)
+            if t % a.interval == 0:
+                key_plan.run()
+            else:
+                model.write_device("data_key", dev_frames[t - 1].data_ptr(), nbytes)
+                cur_plan.run()
+            if gather is not None:
+                gather.submit()
+
+    def sync():
+        if gather is not None:
+            gather.drain()
+        model.ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        frames_total = world * a.steps * a.interval
+        value = frames_total / elapsed
+        out = {"metric": "frames/sec 1024x2048 Accel-%s kf=%d" % (a.version, a.interval), "value": round(value, 3),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": round(value / K80_ACCEL18_FPS, 2) if (a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5) else None,
+               "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80 (includes H2D + label D2H)",
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Accel-%s (R101-DCN key branch + FlowNet-S warp + R%s correction branch + fused score tail), "
+                                      "%dx%d clips, key-frame interval %d, 1 clip (1 key + %d non-key frames) per GPU per step"
+                                      % (a.version, a.version, H, W, a.interval, a.interval - 1),
+                          "frames_per_step_per_gpu": a.interval, "parallelism": "clip-sharded x%d (weights replicated)" % world,
+                          "gather": gather_note, "weights": "seeded random", "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel = conv_igemm_f32 (implicit-GEMM conv on the fp32 matrix cores): HIP-event pair around
+        # every launch on the compute stream, all conv launches of one clip (1 key + 4 non-key plans)
+        kms, cms = key_plan.profile(2), cur_plan.profile(2)
+        fl = ms = n = 0.0
+        for plan, t, wgt in ((key_plan, kms, 1), (cur_plan, cms, a.interval - 1)):
+            for op, d in zip(plan.ops(), t):
+                if op["kind"] == "conv":
+                    fl += wgt * op["flops"]
+                    ms += wgt * float(d)
+                    n += wgt
+        clip_ms = float(kms.sum()) + (a.interval - 1) * float(cms.sum())
+        ach = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": "conv_igemm_f32_kernel (all tile variants)", "launches_per_clip": int(n),
+                           "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
+                           "conv_ms_per_clip": round(ms, 3), "all_kernels_ms_per_clip": round(clip_ms, 3)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.version, a.interval)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
