@@ -116,6 +116,8 @@ struct accel_plan {
     hipGraphExec_t gexec = nullptr;
     bool finalized = false;
     bool allow_graph = true;
+    size_t ws_bytes = 0;            // split-K workspace shared by the plan's convs (stream-ordered)
+    float* ws = nullptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -422,9 +424,19 @@ static int finalize_conv(accel_plan* p, Op& op)
     if (op.d.set) { c.res = op.d.ptr; c.resCs = op.d.Cs; }
     c.Cout_store = cout_store;
     c.M = c.Ho * c.Wo;
+    auto extent = [](const BufRef& r, int cuse) {
+        return (unsigned)((((size_t)r.H * r.W - 1) * r.Cs + cuse) * sizeof(float));
+    };
+    c.x_bytes = extent(op.a, c.Cin > op.a.Cs ? op.a.Cs : c.Cin);
+    c.y_bytes = extent(op.b, cout_store);
+    if (op.c.set) c.y2_bytes = extent(op.c, cout_store);
+    if (op.d.set) c.res_bytes = extent(op.d, cout_store);
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
     c.force_tile = (int)kv_int(kv, "tile", -1);
+    c.no_split = (int)kv_int(kv, "nosplit", 0);
+    const size_t ws = conv_plan_split(c);
+    if (ws > p->ws_bytes) p->ws_bytes = ws;
     return 0;
 }
 
@@ -689,6 +701,11 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     for (Op& op : p->ops) {
         int rc = finalize_op(p, op);
         if (rc) return rc;
+    }
+    if (p->ws_bytes) {
+        HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
+        p->owned.push_back(p->ws);
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = p->ws;
     }
     HIP_TRY(hipDeviceSynchronize());
     const char* g = getenv("ACCEL_HIP_GRAPH");

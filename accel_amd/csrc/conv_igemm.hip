@@ -30,6 +30,38 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Buffer resources: out-of-range offsets return 0 on loads and are dropped on
+// stores, so image borders, ragged tiles and padded K need no branches.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define ACCEL_BUF_FLAGS 0x00020000   // gfx9 raw buffer, 32-bit data format
+#define OOB 0xFFFFFFFFu
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, ACCEL_BUF_FLAGS);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+}
+
+// exact k -> (tap, ci) and tap -> (ky, kx) without integer division
+__device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, int& r)
+{
+    q = (int)((float)a * inv_d);
+    r = a - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
+
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
 {
@@ -50,12 +82,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
     // tile is re-read from that L2 by its neighbours.
     const int nblk = p.MT * p.NT;
     const int bid = blockIdx.x;
-    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int nt = swz % p.NT, mt = swz / p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    int kh = p.kh, kw = p.kw, ph = p.ph, pw = p.pw;
+    int kw = p.kw, ph = p.ph, pw = p.pw;
     const float* wbase = p.w;
     int py = 0, px = 0;
     if (p.deconv2x) {
@@ -63,49 +95,50 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
         ph = 1 - py; pw = 1 - px;
         wbase += (size_t)blockIdx.y * p.w_class_stride;
     }
-    const int ntaps = kh * kw;
+    const int ntaps = p.kh * kw;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
 
     // ---- staging coordinates --------------------------------------------------
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     int a_iy0[AR], a_ix0[AR], a_nb[AR];
-    bool a_ok[AR];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + srow + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_iy0[i] = oy * p.sh - ph;
+        a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);   // invalid rows fail the bounds test below
         a_ix0[i] = ox * p.sw - pw;
         a_nb[i] = n * p.H * p.W;
     }
-    int ci = scol, tap = 0, ky = 0, kx = 0;
-    while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kx == kw) { kx = 0; ++ky; } }
+    // split-K: blockIdx.z owns K steps [kt_begin, kt_end)
+    const int KT_all = p.K_pad / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
+    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
 
     const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
     const size_t wrow_step = (size_t)32 * p.K_pad;
 
     f32x4 ra[AR], rb[BR];
     auto load_tiles = [&](int k0) {
+        int tap, ci, ky, kx;
+        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
+        divmod_small(tap, kw, inv_kw, ky, kx);
+        const int dy = ky * p.dh, dx = kx * p.dw;
+        const bool tap_ok = tap < ntaps;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + ky * p.dh, ix = a_ix0[i] + kx * p.dw;
-            const bool ok = a_ok[i] && tap < ntaps && (unsigned)iy < (unsigned)p.H &&
-                            (unsigned)ix < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(
-                        p.x + ((size_t)(a_nb[i] + iy * p.W + ix) * p.xCs + ci));
-            ra[i] = v;
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
+            ra[i] = buf_load4(xr, off);
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
             rb[i] = *reinterpret_cast<const f32x4*>(wrow0 + i * wrow_step + k0);
-    };
-    auto advance = [&]() {
-        ci += BK;
-        while (ci >= p.Cin) { ci -= p.Cin; ++tap; if (++kx == kw) { kx = 0; ++ky; } }
     };
     auto store_tiles = [&](int buf) {
         float* a = As + buf * BM * LDK;
@@ -126,72 +159,162 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int KT = p.K_pad / BK;
-    load_tiles(0);
+    load_tiles(kt_begin * BK);
     store_tiles(0);
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     int cur = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) { advance(); load_tiles((kt + 1) * BK); }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tiles((kt + 1) * BK);
         const float* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
         const float* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
+        // register double-buffered fragments: t+1 is read from LDS while t feeds the matrix core
+        f32x4 fa[2][MI], fb[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
 #pragma unroll
         for (int t = 0; t < BK / 8; ++t) {
-            f32x4 fa[MI], fb[NI];
+            const int c = t & 1, n = c ^ 1;
+            if (t + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + t * 8);
+                for (int i = 0; i < MI; ++i) fa[n][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (t + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + t * 8);
+                for (int j = 0; j < NI; ++j) fb[n][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (t + 1) * 8);
+            }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][r], fb[c][j][r], acc[i][j], 0, 0, 0);
         }
         if (more) store_tiles(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- fused epilogue ---------------------------------------------------------
+    // ---- output coordinates of this lane's 16*MI accumulator rows ------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (-> co), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
+
+    // ---- split-K: raw partial sums to the workspace [split][class][M][Cout_store] ----
+    if (p.ksplit > 1) {
+        const size_t slab = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)p.M * p.Cout_store;
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.ws + slab, (unsigned)((size_t)p.M * p.Cout_store * 4));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int co = n0 + (wn * NI + j) * 32 + (lane & 31);
+            const bool cok = co < p.Cout_store;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = rbase + i * 32 + (e & 3) + 8 * (e >> 2);
+                    buf_store1(wr, (cok && m < p.M) ? (unsigned)((m * p.Cout_store + co) * 4) : OOB, acc[i][j][e]);
+                }
+        }
+        return;
+    }
+
+    // ---- fused epilogue: scale/shift (+residual) -> activation -> store (+ dual output) ----
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t y2r = make_rsrc(p.y2 ? p.y2 : p.y, p.y2 ? p.y2_bytes : 0u);
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    auto pixel_of = [&](int m) -> unsigned {      // NHWC pixel index of GEMM row m, OOB past M
+        if (m >= p.M) return OOB;
+        if (!p.deconv2x) return (unsigned)m;
+        int n, rem, oy, ox;
+        divmod_small(m, HoWo, inv_howo, n, rem);
+        divmod_small(rem, p.Wo, inv_wo, oy, ox);
+        return (unsigned)((n * p.yH + (2 * oy + py)) * p.yW + (2 * ox + px));
+    };
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int co = n0 + (wn * NI + j) * 32 + (lane & 31);
         const bool cok = co < p.Cout_store;
-        float sc = 1.f, sf = 0.f, sc2 = 1.f, sf2 = 0.f;
-        if (cok) {
-            sc = p.scale[co]; sf = p.shift[co];
-            if (p.y2) { sc2 = p.scale2[co]; sf2 = p.shift2[co]; }
-        }
+        const int cc = cok ? co : 0;
+        const float sc = p.scale[cc], sf = p.shift[cc];
+        const float sc2 = p.y2 ? p.scale2[cc] : 1.f, sf2 = p.y2 ? p.shift2[cc] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * MI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (!cok || m >= p.M) continue;
-                size_t pix = (size_t)m;
-                if (p.deconv2x) {
-                    const int n = m / HoWo, rem = m - n * HoWo;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    pix = ((size_t)n * p.yH + (2 * oy + py)) * p.yW + (2 * ox + px);
+            for (int h = 0; h < 4; ++h) {          // 4 rows at a time keeps the live set small
+                unsigned pix[4];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned px_ = pixel_of(rbase + i * 32 + e + 8 * h);
+                    pix[e] = cok ? px_ : OOB;
+                    v[e] = acc[i][j][h * 4 + e] * sc + sf;
                 }
-                float v = acc[i][j][e] * sc + sf;
-                if (p.res) v += p.res[pix * p.resCs + co];
-                if (p.act == 1) v = fmaxf(v, 0.f);
-                else if (p.act == 2) v = v > 0.f ? v : v * p.slope;
-                p.y[pix * p.yCs + co] = v;
-                if (p.y2) p.y2[pix * p.y2Cs + co] = fmaxf(v * sc2 + sf2, 0.f);
+                if (p.res) {
+                    float rv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        rv[e] = buf_load1(rr, pix[e] != OOB ? (pix[e] * p.resCs + co) * 4u : OOB);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                    else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                    buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co) * 4u : OOB, v[e]);
+                }
+                if (p.y2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co) * 4u : OOB, fmaxf(v[e] * sc2 + sf2, 0.f));
+                }
             }
         }
+    }
+}
+
+// Sum the split-K partials and apply the fused epilogue (one float4 of channels per thread).
+__global__ void splitk_reduce_kernel(ConvParams p, int classes)
+{
+    const int N4 = p.Cout_store / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)classes * p.M * N4) return;
+    const int c4 = (int)(idx % N4);
+    const int m = (int)((idx / N4) % p.M);
+    const int cls = (int)(idx / ((long)N4 * p.M));
+    const size_t slab = (size_t)classes * p.M * p.Cout_store;
+    const float* w = p.ws + ((size_t)cls * p.M + m) * p.Cout_store + c4 * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(w + s * slab);
+    size_t pix = (size_t)m;
+    if (p.deconv2x) {
+        const int HoWo = p.Ho * p.Wo;
+        const int n = m / HoWo, rem = m - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        pix = ((size_t)n * p.yH + (2 * oy + (cls >> 1))) * p.yW + (2 * ox + (cls & 1));
+    }
+    const int co = c4 * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + co);
+    f32x4 v = a * sc + sf;
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.resCs + co);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+        else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+    }
+    *reinterpret_cast<f32x4*>(p.y + pix * p.yCs + co) = v;
+    if (p.y2) {
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.scale2 + co);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.shift2 + co);
+        f32x4 u = v * s2 + b2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = fmaxf(u[e], 0.f);
+        *reinterpret_cast<f32x4*>(p.y2 + pix * p.y2Cs + co) = u;
     }
 }
 
@@ -210,8 +333,12 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1);
+    dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit <= 1) return e;
+    const long total = (long)grid.y * p.M * (p.Cout_store / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, (int)grid.y);
     return hipGetLastError();
 }
 
@@ -227,6 +354,7 @@ int conv_pick_tile(const ConvParams& p)
         return classes * ((p.M + bm - 1) / bm) * (long)((cs + bn - 1) / bn);
     };
     if (cs <= 64) return blocks(128, 64) >= 512 ? 1 : 3; // 128x64 or 64x64
+    if (blocks(128, 128) < 64) return 3;                 // tiny M: small tiles + split-K
     if (cs % 128 == 0 || cs > 256) {
         if (blocks(128, 128) >= 512) return 0;
         if (blocks(128, 64) >= 512) return 1;
@@ -235,6 +363,34 @@ int conv_pick_tile(const ConvParams& p)
     }
     if (blocks(128, 64) >= 512) return 1;
     return 3;
+}
+
+static void tile_dims(int tile, int& bm, int& bn)
+{
+    static const int BMs[5] = {128, 128, 64, 64, 128}, BNs[5] = {128, 64, 128, 64, 32};
+    bm = BMs[tile]; bn = BNs[tile];
+}
+
+// Fill the chip when the output grid alone cannot: split K across blockIdx.z.
+// Returns the workspace bytes the launch needs (0 = no split).
+size_t conv_plan_split(ConvParams& p)
+{
+    p.ksplit = 1; p.kt_per_split = 0;
+    if (p.no_split) return 0;
+    int bm, bn;
+    const int tile = conv_pick_tile(p);
+    tile_dims(tile, bm, bn);
+    const long classes = p.deconv2x ? 4 : 1;
+    const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
+    const int KT = p.K_pad / 32;
+    if (blocks >= 256 || KT < 8) return 0;
+    int want = (int)((768 + blocks - 1) / blocks);
+    int ks = want < KT / 4 ? want : KT / 4;
+    if (ks < 2) return 0;
+    p.kt_per_split = (KT + ks - 1) / ks;
+    p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
+    if (p.ksplit < 2) { p.ksplit = 1; return 0; }
+    return (size_t)p.ksplit * classes * p.M * p.Cout_store * sizeof(float);
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)

@@ -29,10 +29,16 @@ struct ConvParams {
     size_t w_class_stride; // floats between parity classes
     int MT, NT;            // filled by the launcher
     int force_tile;        // -1 = heuristic
+    int ksplit;            // >1: split-K over blockIdx.z, partials in ws, reduce+epilogue kernel follows
+    int kt_per_split;
+    int no_split;
+    float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]
+    unsigned x_bytes, y_bytes, y2_bytes, res_bytes;   // extents of the views (buffer-resource bounds)
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
 int conv_pick_tile(const ConvParams& p);
+size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns workspace bytes
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------
 // NCHW fp32 3xHxW image -> NHWC4 (c3 = 0); optional per-channel scale/shift (bn_data)

@@ -35,6 +35,8 @@ CONV_CASES = [
     (256, 512, 17, 23, 1, 2, 0, 1),      # 1x1 stride-2 shortcut
     (2048, 19, 8, 16, 1, 1, 0, 1),       # score conv
     (8, 8, 1, 1, 3, 1, 1, 1),            # degenerate 1x1 image
+    (512, 1024, 4, 8, 3, 1, 1, 1),       # low-res FlowNet conv6_1 shape: split-K path
+    (1024, 19, 16, 32, 1, 1, 0, 1),      # score conv: narrow N + split-K
 ]
 
 
