@@ -256,7 +256,7 @@ class Lowering(object):
         out = self.dest_for(cur)
         # dual output: relu(bn(.)) of the value for the next pre-activation unit
         out2, bn2, chain2 = None, None, []
-        if id(cur) not in self.head_ids or True:
+        if True:
             for n in self.consumers(cur):
                 if n.op == "BatchNorm" and id(n) not in self.absorbed:
                     c2 = self.consumers(n)
@@ -381,10 +381,16 @@ class Lowering(object):
 
     # ---- warp ---------------------------------------------------------------------------------------
     def lower_warp(self, B):
-        feat, grid = B.inputs
-        if grid.op != "GridGenerator":
-            raise NotImplementedError("BilinearSampler grid must come from GridGenerator(warp)")
-        flow = self.input_view(grid.inputs[0])
+        """GridGenerator(warp)+BilinearSampler, or the registered `FlowWarp` custom op."""
+        if B.op == "Custom":
+            feat, flow_node = B.inputs
+            grid = B
+        else:
+            feat, grid = B.inputs
+            if grid.op != "GridGenerator":
+                raise NotImplementedError("BilinearSampler grid must come from GridGenerator(warp)")
+            flow_node = grid.inputs[0]
+        flow = self.input_view(flow_node)
         fin = self.input_view(feat)
         out = self.dest_for(B)
         _, C, H, W = self.shape(B)
@@ -465,6 +471,11 @@ class Lowering(object):
                 self.lower_pool(n)
             elif op == "BilinearSampler":
                 self.lower_warp(n)
+            elif op == "Custom" and getattr(n.attrs["prop"], "lowering", None) == "warp":
+                self.lower_warp(n)
+            elif op == "Custom":
+                raise NotImplementedError("Custom op %s (%s) runs on the host and cannot sit inside a device plan"
+                                          % (n.name, n.attrs["op_type"]))
             elif op in ("_div_scalar", "GridGenerator"):
                 continue   # absorbed by prep_flow / warp when their consumer is lowered
             elif op == "BatchNorm" and n.inputs[0].op == "null":

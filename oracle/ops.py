@@ -31,6 +31,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
+        # many-core hosts: the oracle's tensors are small, 256 OpenMP threads only add barriers
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 32)))
         _LIB = ctypes.CDLL(build())
         _LIB.orc_pool_out.restype = ctypes.c_int
     return _LIB

@@ -20,7 +20,7 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture
 def demo_cfg():
     """The reference's dff_deeplab_vid_demo.yaml values that the path reads
     (SCALES, PIXEL_MEANS, NUM_CLASSES, NUM_ANCHORS), as committed fixture."""

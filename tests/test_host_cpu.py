@@ -1,0 +1,350 @@
+"""Host logic, no GPU: symbol surface and parameter tables, lowering/plan
+invariants, config overlay, demo helpers, checkpoint IO, operator_py plugin
+surface, C-ABI export check, and the rule that the product path never touches
+the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+
+
+def _sym(version):
+    from accel_amd import symbols
+    name = "accel_" + version
+    return getattr(getattr(symbols, name), name)()
+
+
+def _shapes(H, W, key):
+    return {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": (1, 2048, 1, 1) if key else (1, 2048, H // 16, W // 16)}
+
+
+# ---- symbol surface (accel_18.py:121-239 etc.) ------------------------------------------
+@pytest.mark.parametrize("version", ["18", "34", "50", "101"])
+def test_output_names_and_shapes(demo_cfg, version):
+    inst = _sym(version)
+    key = inst.get_key_test_symbol(demo_cfg)
+    assert key.list_outputs() == ["data_key", "feat_key", "res5c_relu_output", "croped_score_output"]
+    inst.infer_shape(_shapes(256, 512, True))
+    assert inst.out_shape_dict["res5c_relu_output"] == (1, 2048, 16, 32)
+    assert inst.out_shape_dict["croped_score_output"] == (1, 19, 256, 512)
+    cur = inst.get_cur_test_symbol(demo_cfg)
+    last = "croped_score_output" if version == "101" else "correction_output"
+    assert cur.list_outputs() == ["data_key", "warping_feat_output", last]
+    inst.infer_shape(_shapes(256, 512, False))
+    assert inst.out_shape_dict["warping_feat_output"] == (1, 2048, 16, 32)
+    assert inst.out_shape_dict[last] == (1, 19, 256, 512)
+    assert {"data", "data_key", "feat_key"} <= set(cur.list_arguments())
+
+
+def test_parameter_table_accel18(demo_cfg):
+    """names / layouts a reference checkpoint must line up with"""
+    inst = _sym("18")
+    inst.get_cur_test_symbol(demo_cfg)
+    inst.infer_shape(_shapes(128, 256, False))
+    a, x = inst.arg_shape_dict, inst.aux_shape_dict
+    assert a["corr_weight"] == (19, 38, 1, 1) and a["corr_bias"] == (19,)
+    assert a["upsampling_weight"] == (19, 1, 32, 32) and a["18_upsampling_weight"] == (19, 1, 32, 32)
+    assert a["18_feat_upsampling_weight"] == (512, 2048, 4, 4)
+    assert a["fc6_weight"] == (1024, 2048, 1, 1) and a["18_score_weight"] == (19, 1024, 1, 1)
+    assert a["18_res5a_branch2b_offset_weight"] == (72, 512, 3, 3) and a["18_res5a_branch2b_offset_bias"] == (72,)
+    assert a["18_res5a_branch2b_weight"] == (512, 512, 3, 3) and "18_res5a_branch2b_bias" not in a
+    assert a["18_conv0_weight"] == (64, 3, 7, 7) and a["18_stage1_unit1_sc_weight"] == (64, 64, 1, 1)
+    assert a["18_stage3_unit1_conv1_weight"] == (256, 128, 3, 3)
+    assert a["flow_conv1_weight"] == (64, 6, 7, 7) and a["deconv5_weight"] == (1024, 512, 4, 4)
+    assert a["Convolution2_weight"] == (2, 1026, 3, 3) and a["upsample_flow6to5_weight"] == (2, 2, 4, 4)
+    assert a["deconv4_weight"] == (1026, 256, 4, 4) and a["Convolution5_weight"] == (2, 194, 3, 3)
+    assert not any(k.startswith("Convolution5_scale") for k in a)          # dead branch is pruned (ref F7)
+    assert x["18_bn_data_moving_mean"] == (3,) and a["18_bn_data_gamma"] == (3,)
+    assert "18_stage1_unit1_bn1_moving_var" in x and "18_bn5b_branch2b_moving_mean" in x
+    assert "res5a_branch2a_weight" not in a                                 # no R101 trunk in the Accel-18 cur graph
+
+
+def test_parameter_table_r101_and_variants(demo_cfg):
+    inst = _sym("101")
+    inst.get_key_test_symbol(demo_cfg)
+    inst.infer_shape(_shapes(128, 256, True))
+    a = inst.arg_shape_dict
+    assert a["res5a_branch2b_offset_weight"] == (18, 512, 3, 3) and a["res5c_branch2b_weight"] == (512, 512, 3, 3)
+    assert a["res3b3_branch2c_weight"] == (512, 128, 1, 1) and a["res4b22_branch2a_weight"] == (256, 1024, 1, 1)
+    assert "res4b23_branch2a_weight" not in a and "res3b4_branch2a_weight" not in a
+    assert a["res3a_branch1_weight"] == (512, 256, 1, 1) and a["conv1_weight"] == (64, 3, 7, 7)
+    assert len([k for k in a if k.endswith("_weight")]) == 104 + 3 + 3    # 104 trunk convs (3 of them DCN) + 3 offset convs + fc6, score, upsampling
+    inst.get_cur_test_symbol(demo_cfg)
+    inst.infer_shape(_shapes(128, 256, False))
+    assert inst.arg_shape_dict["corr_weight"] == (2048, 4096, 1, 1)
+    i50 = _sym("50")
+    i50.get_cur_test_symbol(demo_cfg)
+    i50.infer_shape(_shapes(128, 256, False))
+    a50 = i50.arg_shape_dict
+    assert a50["curr_fc6_weight"] == (1024, 2048, 1, 1) and a50["curr_upsampling_weight"] == (19, 1, 32, 32)
+    assert a50["50_res5a_branch2b_offset_weight"] == (72, 512, 3, 3) and a50["50_res4f_branch2c_weight"] == (1024, 256, 1, 1)
+    i34 = _sym("34")
+    i34.get_cur_test_symbol(demo_cfg)
+    i34.infer_shape(_shapes(128, 256, False))
+    assert "34_stage3_unit6_conv2_weight" in i34.arg_shape_dict and "34_res5c_branch2b_weight" in i34.arg_shape_dict
+    assert "34_stage3_unit7_conv1_weight" not in i34.arg_shape_dict
+
+
+def test_flownet_shape_trace_1024x2048(demo_cfg):
+    """SURVEY.md appendix B"""
+    from accel_amd.mx.symbol import infer_shapes
+    inst = _sym("18")
+    cur = inst.get_cur_test_symbol(demo_cfg)
+    sh = infer_shapes(cur, _shapes(1024, 2048, False))
+    byname = {n.name: sh[id(n)] for n in cur.topo() if id(n) in sh}
+    exp = {"resize_data": (1, 6, 512, 1024), "flow_conv1": (1, 64, 256, 512), "conv2": (1, 128, 128, 256),
+           "conv3_1": (1, 256, 64, 128), "conv4_1": (1, 512, 32, 64), "conv5_1": (1, 512, 16, 32),
+           "conv6_1": (1, 1024, 8, 16), "deconv5": (1, 512, 18, 34), "crop_deconv5": (1, 512, 16, 32),
+           "Concat2": (1, 1026, 16, 32), "Concat3": (1, 770, 32, 64), "Concat4": (1, 386, 64, 128),
+           "deconv2": (1, 64, 130, 258), "Concat5": (1, 194, 128, 256), "resize_concat5": (1, 194, 64, 128),
+           "Convolution5": (1, 2, 64, 128), "warping_feat": (1, 2048, 64, 128), "18_feat_upsampling": (1, 2048, 64, 128),
+           "18_res5b_relu": (1, 512, 32, 64), "18_croped_score": (1, 19, 1024, 2048)}
+    for k, v in exp.items():
+        assert byname[k] == v, (k, byname[k], v)
+
+
+# ---- lowering invariants -------------------------------------------------------------------
+def _plan(version, key, H=128, W=256):
+    from accel_amd import lower
+    from accel_amd.config.config import config
+    inst = _sym(version)
+    sym = inst.get_key_test_symbol(config) if key else inst.get_cur_test_symbol(config)
+    return lower.lower(sym, _shapes(H, W, key))
+
+
+def test_algorithmic_flops_match_the_survey(demo_cfg):
+    """BASELINE.md section 4 (GFLOP per frame at 1024x2048), within 0.5 %"""
+    exp = {("18", True): 855.3, ("18", False): 381.2, ("34", False): 537.2, ("50", False): 679.3, ("101", False): 1076.8}
+    for (v, key), gf in exp.items():
+        _, lw = _plan(v, key, 1024, 2048)
+        assert abs(lw.total_flops / 1e9 - gf) / gf < 5e-3, (v, key, lw.total_flops / 1e9, gf)
+
+
+@pytest.mark.parametrize("version,key", [("18", True), ("18", False), ("34", False), ("50", False), ("101", False)])
+def test_plan_is_well_formed(demo_cfg, version, key):
+    text, lw = _plan(version, key)
+    written, ranges = set(), []
+    arena = int(re.search(r"^arena bytes=(\d+)", text, re.M).group(1))
+    pbufs = dict(re.findall(r"^pbuf name=(\S+) bytes=(\d+)", text, re.M))
+    for idx, line in enumerate(l for l in text.splitlines() if l and not l.startswith(("#", "arena", "pbuf", "option"))):
+        kv = dict(t.split("=", 1) for t in line.split()[1:])
+        for k, v in kv.items():
+            m = re.match(r"^(\w+):(\d+):(\d+):(\d+):(\d+):(\d+)$", v)
+            if not m:
+                continue
+            space, off, C, Cs, H, W = m.group(1), *map(int, m.groups()[1:])
+            if space == "A":
+                assert off % 16 == 0 and Cs % 4 == 0 and C <= Cs
+                end = off + ((H * W - 1) * Cs + C) * 4
+                assert end <= arena, line
+                rng = (off, off + H * W * Cs * 4)
+                if k in ("out", "out2", "dst"):
+                    written.add(rng)
+                elif k in ("in", "res", "left", "right", "feat", "flow", "off", "src"):
+                    # every arena read must lie inside a region some earlier op wrote
+                    assert any(w0 <= rng[0] and off + ((H * W - 1) * Cs + C) * 4 <= w1 for (w0, w1) in written), line
+            else:
+                assert space in pbufs, line
+    # liveness plan: two buffers alive at the same op never overlap in the arena
+    live = [b for b in lw.bufs if b.first is not None]
+    for i, a in enumerate(live):
+        for b in live[i + 1:]:
+            if not (a.last < b.first or b.last < a.first):
+                assert a.off + a.nbytes <= b.off or b.off + b.nbytes <= a.off, (a.id, b.id)
+    kinds = [k for k, _ in lw.ops]
+    assert kinds.count("score_tail") == 1
+    if not key:
+        assert kinds.count("warp") == 1 and kinds.count("prep_flow") == 1 and kinds.count("copy") == 1
+    assert "Concat" not in text and all(k in ("prep_rgb", "prep_flow", "conv", "pool", "warp", "dcn_cols", "score_tail", "copy") for k in kinds)
+
+
+def test_fusion_of_the_preactivation_units(demo_cfg):
+    _, lw = _plan("18", False)
+    convs = {a["name"]: a for k, a in lw.ops if k == "conv"}
+    sc = convs["18_stage1_unit1_sc"]                      # shortcut conv + residual add, dual output for the next unit
+    assert "res" in sc and sc["bn2"] == "18_stage1_unit2_bn1" and "out2" in sc
+    assert convs["18_stage1_unit1_conv1"]["bn"] == "18_stage1_unit1_bn2" and convs["18_stage1_unit1_conv1"]["act"] == 1
+    pools = [a for k, a in lw.ops if k == "pool" and a["kind"] == "max"]
+    assert pools[0]["bn"] == "18_stage1_unit1_bn1" and pools[0]["act"] == 1
+    rgb = [a for k, a in lw.ops if k == "prep_rgb"]
+    assert rgb[0]["bn"] == "18_bn_data" and rgb[0]["fixg"] == 1
+    assert convs["Convolution5"]["mul"] == 2.5
+    assert convs["deconv5"]["mode"] == "deconv2x" and convs["deconv5"]["act"] == 2
+    assert convs["18_res5a_branch2b"]["mode"] == "cols" and convs["18_res5b_branch2b"]["res"] is not None
+
+
+def test_unsupported_graph_is_rejected_loudly(demo_cfg):
+    from accel_amd import lower, mx
+    d = mx.sym.Variable("data")
+    c = mx.sym.Convolution(data=d, num_filter=8, kernel=(3, 3), num_group=2, name="g")
+    with pytest.raises(NotImplementedError, match="grouped Convolution"):
+        lower.lower(mx.sym.Group([c]), {"data": (1, 4, 128, 128)})
+
+
+# ---- config / demo helpers ------------------------------------------------------------------
+def test_update_config_rules(tmp_path, demo_cfg):
+    from accel_amd.config.config import config, reset_config, update_config
+    assert config.SCALES == [(1024, 2048)] and isinstance(config.network.PIXEL_MEANS, np.ndarray)
+    assert config.network.NUM_ANCHORS == 9                      # sub-keys without a default are added freely
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("NOT_A_KEY: 1\n")
+    with pytest.raises(ValueError, match="key must exist in config.py"):
+        update_config(str(bad))
+    train_like = tmp_path / "t.yaml"
+    train_like.write_text("symbol: accel_18\nTRAIN:\n  KEY_INTERVAL: 5\n  arg_prefix: '18_'\nnetwork:\n  FIXED_PARAMS_SHARED: [conv1]\n")
+    update_config(str(train_like))
+    assert config.symbol == "accel_18" and config.TRAIN.KEY_INTERVAL == 5 and config.network.FIXED_PARAMS_SHARED == ["conv1"]
+    reset_config()
+    assert config.symbol == ""
+
+
+def test_training_yaml_without_num_anchors_still_builds(demo_cfg):
+    from accel_amd.config.config import config
+    config.network.pop("NUM_ANCHORS", None)
+    assert _sym("18").get_key_test_symbol(config).list_outputs()[-1] == "croped_score_output"
+
+
+def test_frame_selection_and_miou_helpers():
+    from accel_amd.demo import fast_hist, per_class_iu, select_frames
+    names = ["f%03d" % i for i in range(90)]
+    sel = select_frames(names, 3, 5, False)
+    assert sel == names[15:20] + names[45:50] + names[75:80]         # offset = interval-1: labelled frame 19 is last
+    sel = select_frames(names, 3, 5, True)
+    assert sel == names[19:24] + names[48:53] + names[77:82]         # --avg: offset = i % interval
+    pred = np.array([0, 1, 1, 2, 2, 2, 0])
+    lab = np.array([0, 1, 2, 2, 2, 255, 1])                           # 255 = ignore
+    h = fast_hist(pred, lab, 3)
+    assert h.tolist() == [[1, 0, 0], [1, 1, 0], [0, 1, 2]]
+    iu = per_class_iu(h)
+    np.testing.assert_allclose(iu, [1 / 2, 1 / 3, 2 / 3])
+    assert round(np.nanmean(per_class_iu(fast_hist(np.zeros(4, int), np.zeros(4, int), 3))) * 100, 2) == 100.0
+
+
+def test_image_transform_and_resize(demo_cfg):
+    from accel_amd.utils.image import resize, transform
+    im = np.random.default_rng(0).integers(0, 255, (1024, 2048, 3)).astype(np.uint8)
+    out, scale = resize(im, 1024, 2048, 0)
+    assert scale == 1.0 and out is im                                  # Cityscapes frames pass through untouched
+    t = transform(im[:4, :6], demo_cfg.network.PIXEL_MEANS)
+    assert t.shape == (1, 3, 4, 6) and t.dtype == np.float64
+    np.testing.assert_allclose(t[0, 0], im[:4, :6, 2] - 123.15)        # channel 0 = R = BGR[2] - means[2]
+    np.testing.assert_allclose(t[0, 2], im[:4, :6, 0] - 103.06)
+    small, s = resize(im[:512, :1024], 1024, 2048, 0)
+    assert s == 2.0 and small.shape == (1024, 2048, 3)
+    padded, _ = resize(im[:100, :130], 100, 130, stride=32)
+    assert padded.shape == (128, 160, 3) and padded[100:].sum() == 0
+
+
+# ---- checkpoint IO -----------------------------------------------------------------------------
+@pytest.mark.parametrize("legacy", [True, False])
+def test_params_roundtrip_and_prefix_rules(tmp_path, legacy):
+    from accel_amd.utils import load_model as L
+    d = {"arg:conv0_weight": np.random.rand(4, 3, 7, 7).astype(np.float32), "arg:fc6_bias_test": np.arange(5, dtype=np.float32),
+         "aux:bn0_moving_mean": np.random.rand(4).astype(np.float32), "arg:18_conv1_weight": np.ones((2, 2), np.float32)}
+    path = str(tmp_path / "m-0003.params")
+    L.nd_save(path, d, legacy=legacy)
+    back = L.nd_load(path)
+    assert set(back) == set(d)
+    for k in d:
+        np.testing.assert_array_equal(back[k], d[k])
+    arg, aux = L.load_param(str(tmp_path / "m"), 3, process=True, argprefix="18_")
+    assert set(arg) == {"18_conv0_weight", "18_fc6_bias", "18_conv1_weight"} and set(aux) == {"18_bn0_moving_mean"}
+    L.save_checkpoint(str(tmp_path / "s"), 0, {"w": d["arg:conv0_weight"]}, {"m": d["aux:bn0_moving_mean"]})
+    a2, x2 = L.load_param(str(tmp_path / "s"), 0)
+    np.testing.assert_array_equal(a2["w"], d["arg:conv0_weight"])
+    np.testing.assert_array_equal(x2["m"], d["aux:bn0_moving_mean"])
+    with open(path, "r+b") as f:
+        f.write(b"\x00" * 8)
+    with pytest.raises(ValueError, match="not an MXNet NDArray-list file"):
+        L.nd_load(path)
+
+
+# ---- operator_py plugin surface ---------------------------------------------------------------
+def test_operator_registration_surface():
+    import accel_amd.operator_py  # noqa: F401  (registers at import, like accel_18.py:11-15)
+    from accel_amd import mx
+
+    @mx.operator.register("scale_by")
+    class ScaleProp(mx.operator.CustomOpProp):
+        def __init__(self, factor="1"):
+            super(ScaleProp, self).__init__(need_top_grad=False)
+            self.factor = float(factor)
+
+        def create_operator(self, ctx, shapes, dtypes):
+            prop = self
+
+            class Op(mx.operator.CustomOp):
+                def forward(self, is_train, req, in_data, out_data, aux):
+                    self.assign(out_data[0], req[0], in_data[0] * prop.factor)
+            return Op()
+
+    assert {"FlowWarp", "tile_as", "scale_by"} <= set(mx.operator.registered())
+    s = mx.sym.Custom(mx.sym.Variable("x"), op_type="scale_by", factor=3)     # params arrive as strings
+    assert s.attrs["params"] == {"factor": "3"} and s.infer_shape(x=(2, 3))[1] == [(2, 3)]
+    op = s.attrs["prop"].create_operator(None, None, None)
+    out = [np.zeros((2, 3))]
+    op.forward(False, ["write"], [np.ones((2, 3))], out, [])
+    np.testing.assert_array_equal(out[0], 3 * np.ones((2, 3)))
+    op.forward(False, ["add"], [np.ones((2, 3))], out, [])
+    np.testing.assert_array_equal(out[0], 6 * np.ones((2, 3)))
+    with pytest.raises(KeyError, match="not registered"):
+        mx.sym.Custom(mx.sym.Variable("x"), op_type="nope")
+    t = mx.sym.Custom(data_shape=mx.sym.Variable("a"), data_content=mx.sym.Variable("b"), op_type="tile_as")
+    assert t.infer_shape(a=(4, 3, 2, 2), b=(1, 5, 7))[1] == [(4, 5, 7)]
+    top = t.attrs["prop"].create_operator(None, None, None)
+    o = [np.zeros((4, 5, 7))]
+    top.forward(False, ["write"], [np.arange(35.0).reshape(1, 5, 7), np.zeros((4, 3, 2, 2))], o, [])
+    assert (o[0][3] == np.arange(35.0).reshape(5, 7)).all()
+
+
+def test_flowwarp_alias_lowers_like_the_stock_pair(demo_cfg):
+    import accel_amd.operator_py  # noqa: F401
+    from accel_amd import lower, mx
+    feat, flow = mx.sym.Variable("feat_key"), mx.sym.Variable("data")
+    shapes = {"feat_key": (1, 2048, 8, 16), "data": (1, 3, 128, 256), "data_key": (1, 3, 128, 256)}
+    pred = mx.sym.Convolution(data=flow, num_filter=2, kernel=(3, 3), stride=(16, 16), pad=(1, 1), name="p")
+    a = mx.sym.BilinearSampler(data=feat, grid=mx.sym.GridGenerator(data=pred, transform_type="warp"), name="warping_feat")
+    b = mx.sym.Custom(data=feat, flow=pred, op_type="FlowWarp", name="warping_feat")
+    ta, _ = lower.lower(mx.sym.Group([a]), shapes)
+    tb, _ = lower.lower(mx.sym.Group([b]), shapes)
+    assert ta == tb and "\nwarp " in ta
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_cabi_exports_every_declared_symbol():
+    from accel_amd import runtime
+    hdr = open(os.path.join(ROOT, "include", "accel_hip.h")).read()
+    declared = set(re.findall(r"\b(accel_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 28
+    lib = ctypes.CDLL(runtime.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libaccel_hip.so does not export %s" % name
+    runtime.lib()
+    assert set(runtime.EXPORTS) <= declared
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from accel_amd import runtime
+    with pytest.raises(runtime.AccelError, match="no HIP device|HIP"):
+        runtime.Context(0)
+    assert runtime.lib().accel_sync(None) != 0 and b"NULL" in runtime.lib().accel_last_error()
+
+
+def test_product_path_never_imports_the_oracle():
+    """only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may use oracle/"""
+    pkg = os.path.join(ROOT, "accel_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|liboracle", src, re.M), os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle", bench)]
+    assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.find("def cpu_baseline"))

@@ -1,0 +1,207 @@
+"""The oracle against (a) torch-CPU wherever torch has an operator of identical
+semantics, (b) hand-derived known-answer cases for the operators torch lacks
+(DeformableConvolution, MXNet 'full' pooling, BilinearSampler border rule),
+(c) the committed golden vectors (guards the oracle against drift).
+
+PARITY UNPINNED: none of this touches the reference's arithmetic (un-vendored
+MXNet); see oracle/accel_oracle.c."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, tol=1e-5):
+    assert a.shape == tuple(b.shape)
+    assert float(np.abs(a - np.asarray(b)).max()) <= tol * max(1.0, float(np.abs(np.asarray(b)).max()))
+
+
+@pytest.mark.parametrize("k,s,p,d", [(1, 1, 0, 1), (3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (5, 2, 2, 1), (7, 2, 3, 1), (1, 2, 0, 1)])
+def test_conv_vs_torch(k, s, p, d):
+    x, w, b = rnd(1, 2, 6, 13, 17), rnd(2, 5, 6, k, k, scale=0.3), rnd(3, 5)
+    close(O.conv2d(x, w, b, s, p, d), F.conv2d(T(x), T(w), T(b), s, p, d).numpy())
+
+
+@pytest.mark.parametrize("k,s,p,g", [(4, 2, 0, 1), (4, 2, 1, 1), (32, 16, 0, 3)])
+def test_deconv_vs_torch(k, s, p, g):
+    x = rnd(4, 1, 6, 5, 7)
+    w = rnd(5, 6, 9 // g if g > 1 else 4, k, k, scale=0.2)
+    cout = w.shape[1] * g
+    b = None if g > 1 else rnd(6, cout)
+    ref = F.conv_transpose2d(T(x), T(w), None if b is None else T(b), s, p, groups=g).numpy()
+    close(O.deconv2d(x, w, b, s, p, g), ref)
+
+
+def test_deconv_p0_crop1_equals_p1():
+    # the identity the lowering relies on: Deconvolution(4x4,s2,p0) + Crop(offset 1,1) == pad 1
+    x, w, b = rnd(7, 1, 5, 6, 9), rnd(8, 5, 3, 4, 4), rnd(9, 3)
+    a = O.crop_like(O.deconv2d(x, w, b, 2, 0), (12, 18), (1, 1))
+    np.testing.assert_array_equal(a, O.deconv2d(x, w, b, 2, 1))
+
+
+@pytest.mark.parametrize("H,W", [(8, 10), (9, 11), (7, 7)])
+def test_pool_vs_torch(H, W):
+    x = rnd(10, 1, 4, H, W)
+    np.testing.assert_array_equal(O.pool2d(x, "max", 3, 2, 0, "full"), F.max_pool2d(T(x), 3, 2, 0, ceil_mode=True).numpy())
+    np.testing.assert_array_equal(O.pool2d(x, "max", 3, 2, 1, "valid"), F.max_pool2d(T(x), 3, 2, 1).numpy())
+    if H % 2 == 0 and W % 2 == 0:   # the only case the BASELINE configs hit: exact 4-means
+        close(O.pool2d(x, "avg", 2, 2, 0, "full"), F.avg_pool2d(T(x), 2, 2).numpy(), 1e-6)
+
+
+def test_pool_full_output_size_rule():
+    # 'full' = ceil: 512 -> 256 with k3 s2 p0 (R101 pool1), the last window is clipped
+    assert O.pool2d(np.zeros((1, 1, 512, 8), np.float32), "max", 3, 2, 0, "full").shape[2] == 256
+    assert O.pool2d(np.zeros((1, 1, 512, 8), np.float32), "max", 3, 2, 1, "valid").shape[2] == 256
+    assert O.pool2d(np.zeros((1, 1, 7, 8), np.float32), "max", 3, 2, 0, "full").shape[2] == 3
+    assert O.pool2d(np.zeros((1, 1, 7, 8), np.float32), "max", 3, 2, 0, "valid").shape[2] == 3
+    assert O.pool2d(np.zeros((1, 1, 8, 8), np.float32), "max", 3, 2, 0, "full").shape[2] == 4
+    assert O.pool2d(np.zeros((1, 1, 8, 8), np.float32), "max", 3, 2, 0, "valid").shape[2] == 3
+
+
+def test_batchnorm_vs_torch():
+    x = rnd(11, 2, 5, 4, 6)
+    g, b, m, v = rnd(12, 5) + 1.5, rnd(13, 5), rnd(14, 5), np.abs(rnd(15, 5)) + 0.5
+    close(O.batchnorm(x, g, b, m, v, 1e-5), F.batch_norm(T(x), T(m), T(v), T(g), T(b), False, 0.0, 1e-5).numpy(), 2e-6)
+    close(O.batchnorm(x, g, b, m, v, 2e-5, fix_gamma=True),
+          F.batch_norm(T(x), T(m), T(v), torch.ones(5), T(b), False, 0.0, 2e-5).numpy(), 2e-6)
+
+
+@pytest.mark.parametrize("mag", [0.0, 0.8, 3.0, 30.0])
+def test_flow_warp_vs_grid_sample(mag):
+    feat, flow = rnd(16, 1, 3, 7, 9), rnd(17, 1, 2, 7, 9, scale=mag)
+    grid = O.grid_generator_warp(flow)
+    ref = F.grid_sample(T(feat), T(grid).permute(0, 2, 3, 1), mode="bilinear", padding_mode="zeros", align_corners=True)
+    close(O.bilinear_sampler(feat, grid), ref.numpy(), 2e-5)
+
+
+def test_flow_warp_known_answers():
+    feat = np.arange(12, dtype=np.float32).reshape(1, 1, 3, 4)
+    z = np.zeros((1, 2, 3, 4), np.float32)
+    close(O.flow_warp(feat, z), feat, 1e-6)                       # zero flow = identity
+    f = z.copy(); f[0, 0] = 1.0                                   # dx = +1: sample the right neighbour
+    out = O.flow_warp(feat, f)
+    np.testing.assert_allclose(out[0, 0, :, :3], feat[0, 0, :, 1:], atol=1e-5)
+    np.testing.assert_allclose(out[0, 0, :, 3], 0.0, atol=1e-5)    # outside -> 0 (zero padding)
+    f = z.copy(); f[0, 1] = -0.5                                  # dy = -0.5: mean of row above and itself
+    out = O.flow_warp(feat, f)
+    np.testing.assert_allclose(out[0, 0, 1], 0.5 * (feat[0, 0, 0] + feat[0, 0, 1]), atol=1e-5)
+    np.testing.assert_allclose(out[0, 0, 0], 0.5 * feat[0, 0, 0], atol=1e-5)   # half of the tap is outside
+
+
+def test_dcn_zero_offsets_equal_dilated_conv():
+    x, w = rnd(18, 1, 8, 9, 10), rnd(19, 6, 8, 3, 3, scale=0.2)
+    for dg in (1, 4):
+        off = np.zeros((1, 18 * dg, 9, 10), np.float32)
+        close(O.deform_conv2d(x, off, w, 1, 2, 2, dg), O.conv2d(x, w, None, 1, 2, 2), 1e-6)
+
+
+def test_dcn_integer_offsets_equal_shifted_taps():
+    # a constant integer offset (dy, dx) on every tap: each tap reads x[h+dy, w+dx], 0 outside the image
+    x, w = rnd(20, 1, 4, 8, 9), rnd(21, 3, 4, 3, 3, scale=0.3)
+    dy, dx = 1, -2
+    H, W = 8, 9
+    off = np.zeros((1, 18, H, W), np.float32)
+    off[0, 0::2], off[0, 1::2] = dy, dx
+    exp = np.zeros((1, 3, H, W), np.float64)
+    for oy in range(H):
+        for ox in range(W):
+            for i in range(3):
+                for j in range(3):
+                    h, ww = oy - 2 + 2 * i + dy, ox - 2 + 2 * j + dx
+                    if 0 <= h < H and 0 <= ww < W:
+                        exp[0, :, oy, ox] += w[:, :, i, j].astype(np.float64) @ x[0, :, h, ww].astype(np.float64)
+    close(O.deform_conv2d(x, off, w, 1, 2, 2, 1), exp.astype(np.float32), 1e-5)
+
+
+def test_dcn_offset_channel_order_and_groups():
+    # dg=2: group 0 gets dx=+1 on tap (1,1) only, group 1 untouched; 1x1-like weight isolates taps
+    C, H, W = 4, 5, 6
+    x = rnd(22, 1, C, H, W)
+    w = np.zeros((1, C, 3, 3), np.float32)
+    w[0, :, 1, 1] = 1.0                                            # centre tap only: y = sum_c sample(c)
+    off = np.zeros((1, 36, H, W), np.float32)
+    off[0, 2 * 4 + 1] = 1.0                                        # group 0, tap index 4 (i=1,j=1), x-offset channel
+    out = O.deform_conv2d(x, off, w, 1, 1, 1, 2)                   # pad 1 dil 1: centre tap samples (y, x)
+    exp = np.zeros((H, W), np.float32)
+    exp[:, :W - 1] += x[0, 0, :, 1:] + x[0, 1, :, 1:]              # channels 0,1 (group 0) shifted by +1 in x
+    exp += x[0, 2] + x[0, 3]                                       # group 1 unshifted
+    np.testing.assert_allclose(out[0, 0], exp, atol=1e-5)
+
+
+def test_dcn_border_rule():
+    """DCN-v1 rule (MXNet deformable_im2col.cuh): a sample is 0 unless 0 <= h < H and
+    0 <= w < W (so h in (-1, 0) is ZERO, unlike torchvision); for h in [H-1, H) the
+    high neighbour clamps to row H-1 with full weight."""
+    H = W = 4
+    x = np.arange(16, dtype=np.float32).reshape(1, 1, H, W) + 1
+    w = np.zeros((1, 1, 3, 3), np.float32)
+    w[0, 0, 1, 1] = 1.0
+
+    def centre(dy, dx):
+        off = np.zeros((1, 18, H, W), np.float32)
+        off[0, 8], off[0, 9] = dy, dx
+        return O.deform_conv2d(x, off, w, 1, 1, 1, 1)[0, 0]
+    np.testing.assert_allclose(centre(-0.5, 0)[0], 0.0)            # h = -0.5 -> 0, not half of row 0
+    np.testing.assert_allclose(centre(-0.5, 0)[1], 0.5 * (x[0, 0, 0] + x[0, 0, 1]))
+    np.testing.assert_allclose(centre(0.5, 0)[3], x[0, 0, 3])      # h = 3.5 in [H-1, H): row H-1, full weight
+    np.testing.assert_allclose(centre(1.0, 0)[3], 0.0)             # h = 4.0 = H -> 0
+    np.testing.assert_allclose(centre(0, 0.25)[:, 3], x[0, 0, :, 3])
+    np.testing.assert_allclose(centre(0, -0.25)[:, 0], 0.0)
+
+
+def test_argmax_first_max_and_uint8():
+    x = np.zeros((1, 19, 2, 3), np.float32)
+    x[0, 7] = 1
+    x[0, 11] = 1
+    out = O.argmax_c(x)
+    assert out.dtype == np.uint8 and (out == 7).all()
+    np.testing.assert_array_equal(out[0], np.argmax(x[0], axis=0))
+
+
+def test_golden_op_vectors_reproduce():
+    from accel_amd.utils import synth
+    g = np.load(os.path.join(GOLD, "ops_golden.npz"))
+    x, w, b = g["conv3x3_s1_x"], g["conv3x3_s1_w"], g["conv3x3_s1_b"]
+    np.testing.assert_array_equal(O.conv2d(x, w, b, 1, 1, 1), g["conv3x3_s1_y"])
+    np.testing.assert_array_equal(O.conv2d(x, w, b, 2, 1, 1), g["conv3x3_s2_y"])
+    np.testing.assert_array_equal(O.conv2d(x, w, b, 1, 2, 2), g["conv3x3_d2_y"])
+    np.testing.assert_array_equal(O.conv2d(x, g["conv7x7_w"], None, 2, 3, 1), g["conv7x7_s2_y"])
+    np.testing.assert_array_equal(O.deconv2d(x, g["deconv4_w"], g["deconv4_b"], 2, 0), g["deconv4_p0_y"])
+    np.testing.assert_array_equal(O.deconv2d(x, g["deconv4_w"], g["deconv4_b"], 2, 1), g["deconv4_p1_y"])
+    up = O.crop_like(O.deconv2d(g["up_s"], synth.bilinear_kernel(3, 32), None, 16, 0, groups=3), (32, 48), (8, 8))
+    np.testing.assert_array_equal(up, g["up_y"])
+    np.testing.assert_array_equal(O.pool2d(g["pool_x"], "max", 3, 2, 0, "full"), g["pool_max_full_y"])
+    np.testing.assert_array_equal(O.pool2d(g["pool_x"], "max", 3, 2, 1, "valid"), g["pool_max_valid_p1_y"])
+    np.testing.assert_array_equal(O.pool2d(g["pool_x"], "avg", 2, 2, 0, "full"), g["pool_avg_full_y"])
+    np.testing.assert_array_equal(O.batchnorm(g["pool_x"], g["bn_g"], g["bn_b"], g["bn_m"], g["bn_v"], 1e-5), g["bn_y"])
+    np.testing.assert_array_equal(O.flow_warp(g["warp_feat"], g["warp_flow"]), g["warp_y"])
+    for dg in (1, 4):
+        np.testing.assert_array_equal(O.deform_conv2d(g["dcn_x"], g["dcn_off_dg%d" % dg], g["dcn_w"], 1, 2, 2, dg),
+                                      g["dcn_y_dg%d" % dg])
+
+
+def test_golden_chain_reproduces_accel18(demo_cfg):
+    """whole key -> cur -> cur -> key chain of Accel-18 at 128x256 from the seed rule"""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden
+    g = np.load(os.path.join(GOLD, "chain_accel18_128x256.npz"))
+    new = make_golden.chain("18")
+    assert str(g["weights_sha256"]) == str(new["weights_sha256"])
+    np.testing.assert_array_equal(new["frames"], g["frames"])
+    np.testing.assert_array_equal(new["labels"], g["labels"])
+    np.testing.assert_allclose(new["logits_sub4"], g["logits_sub4"], rtol=0, atol=1e-4)
