@@ -116,6 +116,7 @@ struct accel_plan {
     hipGraphExec_t gexec = nullptr;
     bool finalized = false;
     bool allow_graph = true;
+    bool allow_tune = true;
     size_t ws_bytes = 0;            // split-K workspace shared by the plan's convs (stream-ordered)
     float* ws = nullptr;
 };
@@ -224,7 +225,11 @@ static int parse_plan(accel_plan* p, const char* text)
             if (eq == std::string::npos) return fail(ACCEL_ERR_PLAN, "line %d: token '%s' is not key=value", lineno, tok.c_str());
             kv[tok.substr(0, eq)] = tok.substr(eq + 1);
         }
-        if (kind == "option") { if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0; continue; }
+        if (kind == "option") {
+            if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0;
+            if (kv_has(kv, "tune")) p->allow_tune = kv_int(kv, "tune", 1) != 0;
+            continue;
+        }
         if (kind == "arena") { p->arena_bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10); continue; }
         if (kind == "pbuf") {
             const std::string name = kv_str(kv, "name");
@@ -435,6 +440,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.slope = (float)kv_f(kv, "slope", 0.1);
     c.force_tile = (int)kv_int(kv, "tile", -1);
     c.no_split = (int)kv_int(kv, "nosplit", 0);
+    c.split_target = 0;
     const size_t ws = conv_plan_split(c);
     if (ws > p->ws_bytes) p->ws_bytes = ws;
     return 0;
@@ -594,6 +600,96 @@ static int run_eager(accel_plan* p)
 }
 
 // ---------------------------------------------------------------------------
+// Per-shape autotuning of the conv launch geometry (tile variant x split-K
+// policy), timed on the real buffers at finalisation.  All candidates compute
+// the same contraction; only the schedule differs.  ACCEL_AUTOTUNE=0 keeps the
+// static heuristic.
+// ---------------------------------------------------------------------------
+struct TuneKey {
+    int v[16];
+    bool operator<(const TuneKey& o) const { return memcmp(v, o.v, sizeof v) < 0; }
+};
+struct TuneVal { int tile, split_target, no_split; };
+static std::map<TuneKey, TuneVal> g_tune_cache;
+
+static size_t conv_apply(ConvParams& c, int tile, int split_target, int no_split)
+{
+    c.force_tile = tile; c.split_target = split_target; c.no_split = no_split;
+    return conv_plan_split(c);
+}
+
+static int autotune_plan(accel_plan* p)
+{
+    const char* e = getenv("ACCEL_AUTOTUNE");
+    if (e && e[0] == '0') return 0;
+    hipStream_t st = p->m->ctx->stream;
+    struct Cand { int tile, split_target, no_split; };
+    // pass 1: workspace large enough for every candidate
+    std::vector<std::vector<Cand>> cands(p->ops.size());
+    size_t ws_need = p->ws_bytes;
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        Op& op = p->ops[i];
+        if (op.kind != OP_CONV || op.conv.force_tile >= 0) continue;
+        ConvParams c = op.conv;
+        std::vector<Cand>& cs = cands[i];
+        if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({3, 0, 0}); }
+        else {
+            static const int tiles[] = {0, 1, 2, 3, 10, 11, 12};   // BK-64 variants (13, 14) need K_pad % 64 == 0: experiments only
+            for (int t : tiles) {
+                cs.push_back({t, 0, 0});
+                ConvParams q = c;
+                const size_t base = conv_apply(q, t, 0, 0);
+                const int ks0 = q.ksplit;
+                if (conv_apply(q, t, 1024, 0) && q.ksplit != ks0) cs.push_back({t, 1024, 0});
+                if (base) cs.push_back({t, 0, 1});
+            }
+        }
+        for (const Cand& k : cs) { ConvParams q = c; size_t w = conv_apply(q, k.tile, k.split_target, k.no_split); if (w > ws_need) ws_need = w; }
+    }
+    if (ws_need > p->ws_bytes) {
+        float* nw = nullptr;
+        HIP_TRY(hipMalloc((void**)&nw, ws_need));
+        p->owned.push_back(nw);
+        p->ws = nw; p->ws_bytes = ws_need;
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = nw;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = 0;
+    for (size_t i = 0; i < p->ops.size() && !rc; ++i) {
+        if (cands[i].empty()) continue;
+        Op& op = p->ops[i];
+        ConvParams& c = op.conv;
+        TuneKey key; memset(&key, 0, sizeof key);
+        int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x, c.ph * 16 + c.pw};
+        memcpy(key.v, kk, sizeof kk);
+        auto it = g_tune_cache.find(key);
+        if (it == g_tune_cache.end()) {
+            float best = 1e30f; TuneVal bv = {c.force_tile, 0, 0};
+            for (const Cand& k : cands[i]) {
+                ConvParams q = c;
+                conv_apply(q, k.tile, k.split_target, k.no_split);
+                hipError_t he = hipSuccess;
+                for (int w = 0; w < 2 && he == hipSuccess; ++w) he = launch_conv_igemm(q, st);   // warm-up
+                HIP_TRY(hipEventRecord(e0, st));
+                for (int r = 0; r < 4 && he == hipSuccess; ++r) he = launch_conv_igemm(q, st);
+                HIP_TRY(hipEventRecord(e1, st));
+                HIP_TRY(hipEventSynchronize(e1));
+                if (he != hipSuccess) { rc = fail(ACCEL_ERR_HIP, "autotune launch failed: %s", hipGetErrorString(he)); break; }
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; bv = {k.tile, k.split_target, k.no_split}; }
+            }
+            it = g_tune_cache.insert({key, bv}).first;
+        }
+        conv_apply(c, it->second.tile, it->second.split_target, it->second.no_split);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
@@ -708,6 +804,7 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = p->ws;
     }
     HIP_TRY(hipDeviceSynchronize());
+    if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
     const char* g = getenv("ACCEL_HIP_GRAPH");
     const bool use_graph = p->allow_graph && !(g && g[0] == '0');
     if (use_graph) {
@@ -916,7 +1013,7 @@ extern "C" int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H,
     const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
     const size_t o_r = off; if (residual) off += al((size_t)Ho * Wo * Kp * 4);
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << off << "\n";
+    s << "option graph=0 tune=0\narena bytes=" << off << "\n";
     s << "pbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
     if (residual) s << "pbuf name=r bytes=" << yout << "\n";
     s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
@@ -950,7 +1047,7 @@ extern "C" int accel_deconv2d_4x4s2(accel_ctx* ctx, const float* x, int N, int C
     const size_t xin = (size_t)C * H * W * 4, yout = (size_t)K * Ho * Wo * 4;
     const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Kp * 4);
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
     s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
     s << "conv name=op mode=deconv2x in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, K, Kp, Ho, Wo)
       << " w=w_weight" << (bias ? " bias=w_bias" : "") << " act=" << act << " slope=" << slope
@@ -983,7 +1080,7 @@ extern "C" int accel_deform_conv2d(accel_ctx* ctx, const float* x, int N, int C,
     const size_t o_c = off; off += al((size_t)Ho * Wo * CC * 4);
     const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << off << "\npbuf name=x bytes=" << xin << "\npbuf name=o bytes=" << oin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "option graph=0 tune=0\narena bytes=" << off << "\npbuf name=x bytes=" << xin << "\npbuf name=o bytes=" << oin << "\npbuf name=y bytes=" << yout << "\n";
     s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
     s << "import_nchw src=" << bref("o", 0, OC, OC, Ho, Wo) << " dst=" << bref("A", o_o, OC, OCp, Ho, Wo) << "\n";
     s << "dcn_cols in=" << bref("A", o_x, C, Cp, H, W) << " off=" << bref("A", o_o, OC, OCp, Ho, Wo)
@@ -1021,7 +1118,7 @@ extern "C" int accel_pool2d(accel_ctx* ctx, const float* x, int N, int C, int H,
     const size_t xin = (size_t)C * H * W * 4, yout = (size_t)C * Ho * Wo * 4;
     const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Cp * 4);
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
+    s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
     s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
     s << "pool in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, C, Cp, Ho, Wo)
       << " kind=" << (is_max ? "max" : "avg") << " k=" << kh << "," << kw << " s=" << sh << "," << sw
@@ -1044,7 +1141,7 @@ extern "C" int accel_flow_warp(accel_ctx* ctx, const float* feat, int C, int H, 
     const size_t fb = (size_t)C * H * W * 4, flb = (size_t)2 * H * W * 4;
     const size_t o_f = 0, o_fl = al(fb), o_o = o_fl + al((size_t)H * W * 16), tot = o_o + al(fb);
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << tot << "\npbuf name=f bytes=" << fb << "\npbuf name=fl bytes=" << flb << "\npbuf name=y bytes=" << fb << "\n";
+    s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=f bytes=" << fb << "\npbuf name=fl bytes=" << flb << "\npbuf name=y bytes=" << fb << "\n";
     s << "import_nchw src=" << bref("f", 0, C, C, H, W) << " dst=" << bref("A", o_f, C, C, H, W) << "\n";
     s << "import_nchw src=" << bref("fl", 0, 2, 2, H, W) << " dst=" << bref("A", o_fl, 2, 4, H, W) << "\n";
     s << "warp feat=" << bref("A", o_f, C, C, H, W) << " flow=" << bref("A", o_fl, 2, 4, H, W) << " out=" << bref("A", o_o, C, C, H, W) << "\n";
@@ -1072,7 +1169,7 @@ extern "C" int accel_score_fuse(accel_ctx* ctx, const float* left, const float* 
     const size_t sb = (size_t)ncls * Hs * Ws * 4, lb = (size_t)ncls * H * W * 4, yb = (size_t)H * W;
     const size_t o_l = 0, o_r = al((size_t)Hs * Ws * Cp * 4), tot = 2 * o_r;
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << tot << "\npbuf name=l bytes=" << sb << "\npbuf name=r bytes=" << sb
+    s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=l bytes=" << sb << "\npbuf name=r bytes=" << sb
       << "\npbuf name=logits bytes=" << lb << "\npbuf name=labels bytes=" << al(yb) << "\n";
     s << "import_nchw src=" << bref("l", 0, ncls, ncls, Hs, Ws) << " dst=" << bref("A", o_l, ncls, Cp, Hs, Ws) << "\n";
     if (right) s << "import_nchw src=" << bref("r", 0, ncls, ncls, Hs, Ws) << " dst=" << bref("A", o_r, ncls, Cp, Hs, Ws) << "\n";
@@ -1117,7 +1214,7 @@ extern "C" int accel_flow_input(accel_ctx* ctx, const float* cur, const float* p
     if ((rc = accel_model_create(ctx, &t.m))) return rc;
     const size_t ib = (size_t)3 * H * W * 4, ob = (size_t)6 * (H / 2) * (W / 2) * 4;
     std::stringstream s;
-    s << "option graph=0\narena bytes=" << al((size_t)(H / 2) * (W / 2) * 32) << "\npbuf name=data bytes=" << ib << "\npbuf name=data_key bytes=" << ib
+    s << "option graph=0 tune=0\narena bytes=" << al((size_t)(H / 2) * (W / 2) * 32) << "\npbuf name=data bytes=" << ib << "\npbuf name=data_key bytes=" << ib
       << "\npbuf name=y bytes=" << ob << "\n";
     s << "prep_flow cur=" << bref("data", 0, 3, 4, H, W) << " prev=" << bref("data_key", 0, 3, 4, H, W)
       << " dst=" << bref("A", 0, 6, 8, H / 2, W / 2) << " H=" << H << " W=" << W << "\n";

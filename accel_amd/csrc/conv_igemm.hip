@@ -25,6 +25,7 @@
 // 2x2 sub-pixel convolutions (blockIdx.y = output parity class) whose results
 // interleave into the 2x-upsampled output.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -62,13 +63,16 @@ __device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, 
     else if (r >= d) { ++q; r -= d; }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvParams p)
 {
-    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int LDK = BK + 4;
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int CPR = BK / 4;                     // float4 columns per staged row
+    constexpr int RP = NTHR / CPR;                  // rows staged per pass
     constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
-    constexpr int AR = BM / 32, BR = BN / 32;       // rows each thread stages
-    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int AR = BM / RP, BR = BN / RP;       // rows each thread stages
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
@@ -99,12 +103,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
 
     // ---- staging coordinates --------------------------------------------------
-    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int srow = tid / CPR, scol = (tid % CPR) * 4;
     int a_iy0[AR], a_ix0[AR], a_nb[AR];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + RP * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int n = mm / HoWo, rem = mm - n * HoWo;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
     const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
 
     const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
-    const size_t wrow_step = (size_t)32 * p.K_pad;
+    const size_t wrow_step = (size_t)RP * p.K_pad;
 
     f32x4 ra[AR], rb[BR];
     auto load_tiles = [&](int k0) {
@@ -145,10 +149,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
         float* b = Bs + buf * BN * LDK;
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(a + (srow + 32 * i) * LDK + scol) = ra[i];
+            *reinterpret_cast<f32x4*>(a + (srow + RP * i) * LDK + scol) = ra[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(b + (srow + 32 * i) * LDK + scol) = rb[i];
+            *reinterpret_cast<f32x4*>(b + (srow + RP * i) * LDK + scol) = rb[i];
     };
 
     f32x16 acc[MI][NI];
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
+        const bool more = (ABL & 1) ? false : kt + 1 < kt_end;   // ABL bit0: no global loads / LDS stores in the loop
         if (more) load_tiles((kt + 1) * BK);
         const float* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
         const float* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
 #pragma unroll
         for (int t = 0; t < BK / 8; ++t) {
             const int c = t & 1, n = c ^ 1;
+            // the other LDS buffer was last read before the previous barrier, so the next tile can
+            // be written into it in the middle of this tile's MFMA burst instead of serialising at the end
+            if (MID && more && t == BK / 16) store_tiles(cur ^ 1);
             if (t + 1 < BK / 8) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[n][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (t + 1) * 8);
@@ -193,9 +200,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvParams p)
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][r], fb[c][j][r], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (!MID && more) store_tiles(cur ^ 1);
+        if (!(ABL & 2)) __syncthreads();                          // ABL bit1: no barrier
+        if (!(ABL & 1)) cur ^= 1;
     }
 
     // ---- output coordinates of this lane's 16*MI accumulator rows ------------------
@@ -318,23 +325,23 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0>
 static hipError_t launch_cfg(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL>), grid, dim3(64 * WGM * WGN), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     const long total = (long)grid.y * p.M * (p.Cout_store / 4);
@@ -367,7 +374,9 @@ int conv_pick_tile(const ConvParams& p)
 
 static void tile_dims(int tile, int& bm, int& bn)
 {
-    static const int BMs[5] = {128, 128, 64, 64, 128}, BNs[5] = {128, 64, 128, 64, 32};
+    static const int BMs[15] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128};
+    static const int BNs[15] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128};
+    if (tile < 0 || tile > 14) tile = 3;
     bm = BMs[tile]; bn = BNs[tile];
 }
 
@@ -383,9 +392,12 @@ size_t conv_plan_split(ConvParams& p)
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
     const int KT = p.K_pad / 32;
-    if (blocks >= 256 || KT < 8) return 0;
-    int want = (int)((768 + blocks - 1) / blocks);
-    int ks = want < KT / 4 ? want : KT / 4;
+    const int min_blocks = p.split_target > 0 ? p.split_target : 256;
+    const int target = p.split_target > 0 ? p.split_target : 768;
+    const int min_steps = 4;
+    if (blocks >= min_blocks || KT < 2 * min_steps) return 0;
+    int want = (int)((target + blocks - 1) / blocks);
+    int ks = want < KT / min_steps ? want : KT / min_steps;
     if (ks < 2) return 0;
     p.kt_per_split = (KT + ks - 1) / ks;
     p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
@@ -395,11 +407,27 @@ size_t conv_plan_split(ConvParams& p)
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
 {
+    // tile ids: t % 5 = geometry {128x128, 128x64, 64x128, 64x64, 128x32}; +5 mid-loop LDS write;
+    // +10 = 8-wave / BK-64 experiments (same geometry order)
     switch (conv_pick_tile(p)) {
-        case 0: return launch_cfg<128, 128, 2, 2>(p, st);
-        case 1: return launch_cfg<128, 64, 2, 2>(p, st);
-        case 2: return launch_cfg<64, 128, 2, 2>(p, st);
-        case 3: return launch_cfg<64, 64, 2, 2>(p, st);
-        default: return launch_cfg<128, 32, 4, 1>(p, st);
+        case 0: return launch_cfg<128, 128, 2, 2, 32, 0>(p, st);
+        case 1: return launch_cfg<128, 64, 2, 2, 32, 0>(p, st);
+        case 2: return launch_cfg<64, 128, 2, 2, 32, 0>(p, st);
+        case 3: return launch_cfg<64, 64, 2, 2, 32, 0>(p, st);
+        case 4: return launch_cfg<128, 32, 4, 1, 32, 0>(p, st);
+        case 5: return launch_cfg<128, 128, 2, 2, 32, 1>(p, st);
+        case 6: return launch_cfg<128, 64, 2, 2, 32, 1>(p, st);
+        case 7: return launch_cfg<64, 128, 2, 2, 32, 1>(p, st);
+        case 8: return launch_cfg<64, 64, 2, 2, 32, 1>(p, st);
+        case 9: return launch_cfg<128, 32, 4, 1, 32, 1>(p, st);
+        case 10: return launch_cfg<128, 128, 2, 4, 32, 1>(p, st);   // 8 waves, wave tile 64x32
+        case 11: return launch_cfg<128, 64, 4, 2, 32, 1>(p, st);    // 8 waves, wave tile 32x32
+        case 12: return launch_cfg<64, 128, 2, 4, 32, 1>(p, st);    // 8 waves, wave tile 32x32
+        case 13: return launch_cfg<64, 64, 2, 2, 64, 1>(p, st);     // BK 64
+        case 14: return launch_cfg<128, 128, 2, 2, 64, 1>(p, st);   // BK 64
+        case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
+        case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier
+        case 22: return launch_cfg<128, 128, 2, 2, 32, 0, 2>(p, st);   // ablation: no barrier (racy, timing only)
+        default: return launch_cfg<64, 64, 2, 2, 32, 0, 3>(p, st);     // 23
     }
 }

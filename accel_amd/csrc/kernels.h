@@ -32,6 +32,7 @@ struct ConvParams {
     int ksplit;            // >1: split-K over blockIdx.z, partials in ws, reduce+epilogue kernel follows
     int kt_per_split;
     int no_split;
+    int split_target;      // >0: split K until the grid has about this many blocks (autotuner)
     float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]
     unsigned x_bytes, y_bytes, y2_bytes, res_bytes;   // extents of the views (buffer-resource bounds)
 };
