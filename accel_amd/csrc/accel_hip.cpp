@@ -438,6 +438,24 @@ static int finalize_conv(accel_plan* p, Op& op)
     if (op.d.set) c.res_bytes = extent(op.d, cout_store);
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
+    c.w_bytes = (unsigned)((size_t)rows * c.K_pad * sizeof(float));
+    if (c.Cin % 32 == 0) {
+        // tap table for the wave-uniform fast path: K step -> (dy, dx, byte offset relative to tap 0)
+        const int KT = c.K_pad / 32, classes = c.deconv2x ? 4 : 1;
+        std::vector<int> tab((size_t)classes * KT * 4, 0);
+        for (int cls = 0; cls < classes; ++cls)
+            for (int kt = 0; kt < KT; ++kt) {
+                const int k = kt * 32, tap = k / c.Cin, ci = k % c.Cin;
+                const int ky = tap / c.kw, kx = tap % c.kw;
+                int* t = &tab[((size_t)cls * KT + kt) * 4];
+                if (tap >= c.kh * c.kw) { t[0] = -(1 << 28); t[1] = 0; t[2] = 0; continue; }   // padded K: always out of range
+                t[0] = ky * c.dh; t[1] = kx * c.dw;
+                t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * 4;
+            }
+        void* dt = nullptr;
+        if ((rc = dev_upload(p, tab.data(), tab.size() * sizeof(int), &dt))) return rc;
+        c.ktab = static_cast<const int4*>(dt);
+    }
     c.force_tile = (int)kv_int(kv, "tile", -1);
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;

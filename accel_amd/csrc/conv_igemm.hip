@@ -63,7 +63,7 @@ __device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, 
     else if (r >= d) { ++q; r -= d; }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0, int FAST = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvParams p)
 {
     constexpr int LDK = BK + 4;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     // ---- staging coordinates --------------------------------------------------
     const int srow = tid / CPR, scol = (tid % CPR) * 4;
     int a_iy0[AR], a_ix0[AR], a_nb[AR];
+    unsigned a_off[AR];                     // FAST: byte offset of (row, tap 0, ci = scol), may wrap below 0 at the border
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
         a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);   // invalid rows fail the bounds test below
         a_ix0[i] = ox * p.sw - pw;
         a_nb[i] = n * p.H * p.W;
+        a_off[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs + scol) * 4);
     }
     // split-K: blockIdx.z owns K steps [kt_begin, kt_end)
     const int KT_all = p.K_pad / BK;
@@ -125,9 +127,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
 
     const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
     const size_t wrow_step = (size_t)RP * p.K_pad;
+    // FAST path (Cin % BK == 0): a K step never straddles two taps, so (dy, dx, byte offset) of the
+    // step is wave-uniform and comes from a host-built table through the scalar unit; weights are
+    // fetched through a buffer resource with the K offset in an SGPR (no per-step vector address math).
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(wbase, p.w_bytes);
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 4);
 
     f32x4 ra[AR], rb[BR];
     auto load_tiles = [&](int k0) {
+        if (FAST) {
+            const int4 tk = p.ktab[(p.deconv2x ? blockIdx.y * KT_all : 0) + k0 / BK];   // {dy, dx, byte offset, 0}
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ra[i] = buf_load4(xr, ok ? a_off[i] + (unsigned)tk.z : OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 4, 0));
+            return;
+        }
         int tap, ci, ky, kx;
         divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
         divmod_small(tap, kw, inv_kw, ky, kx);
@@ -171,7 +193,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (ABL & 1) ? false : kt + 1 < kt_end;   // ABL bit0: no global loads / LDS stores in the loop
-        if (more) load_tiles((kt + 1) * BK);
+        if (more && !(ABL & 8)) load_tiles((kt + 1) * BK);       // ABL bit3: LDS stores of stale registers, no loads
         const float* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
         const float* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
         // register double-buffered fragments: t+1 is read from LDS while t feeds the matrix core
@@ -185,7 +207,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
             const int c = t & 1, n = c ^ 1;
             // the other LDS buffer was last read before the previous barrier, so the next tile can
             // be written into it in the middle of this tile's MFMA burst instead of serialising at the end
-            if (MID && more && t == BK / 16) store_tiles(cur ^ 1);
+            if (MID && more && t == BK / 16 && !(ABL & 4)) store_tiles(cur ^ 1);
             if (t + 1 < BK / 8) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[n][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (t + 1) * 8);
@@ -200,7 +222,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][r], fb[c][j][r], acc[i][j], 0, 0, 0);
         }
-        if (!MID && more) store_tiles(cur ^ 1);
+        if (!MID && more && !(ABL & 4)) store_tiles(cur ^ 1);
+        if (ABL & 4) {                                            // ABL bit2: loads issued and waited for, no LDS stores
+#pragma unroll
+            for (int i = 0; i < AR; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+            for (int i = 0; i < BR; ++i) asm volatile("" ::"v"(rb[i]));
+        }
         if (!(ABL & 2)) __syncthreads();                          // ABL bit1: no barrier
         if (!(ABL & 1)) cur ^= 1;
     }
@@ -325,8 +353,18 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
     }
 }
 
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0, int FAST = 0>
+static hipError_t launch_cfg2(const ConvParams& p0, hipStream_t st);
+
 template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0>
 static hipError_t launch_cfg(const ConvParams& p0, hipStream_t st)
+{
+    if (p0.ktab && p0.Cin % BK == 0) return launch_cfg2<BM, BN, WGM, WGN, BK, MID, ABL, 1>(p0, st);
+    return launch_cfg2<BM, BN, WGM, WGN, BK, MID, ABL, 0>(p0, st);
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL, int FAST>
+static hipError_t launch_cfg2(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
@@ -335,13 +373,13 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t st)
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL>),
+            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL, FAST>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL>), grid, dim3(64 * WGM * WGN), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL, FAST>), grid, dim3(64 * WGM * WGN), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     const long total = (long)grid.y * p.M * (p.Cout_store / 4);
@@ -376,6 +414,7 @@ static void tile_dims(int tile, int& bm, int& bn)
 {
     static const int BMs[15] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128};
     static const int BNs[15] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128};
+    if (tile >= 20) tile = (tile == 23 || tile >= 26) ? 3 : 0;
     if (tile < 0 || tile > 14) tile = 3;
     bm = BMs[tile]; bn = BNs[tile];
 }
@@ -428,6 +467,11 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
         case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier
         case 22: return launch_cfg<128, 128, 2, 2, 32, 0, 2>(p, st);   // ablation: no barrier (racy, timing only)
-        default: return launch_cfg<64, 64, 2, 2, 32, 0, 3>(p, st);     // 23
+        case 23: return launch_cfg<64, 64, 2, 2, 32, 0, 3>(p, st);
+        case 24: return launch_cfg<128, 128, 2, 2, 32, 0, 4>(p, st);   // ablation: loads but no LDS stores
+        case 25: return launch_cfg<128, 128, 2, 2, 32, 0, 8>(p, st);   // ablation: LDS stores but no loads
+        case 26: return launch_cfg<64, 64, 2, 2, 32, 0, 4>(p, st);
+        case 27: return launch_cfg<64, 64, 2, 2, 32, 0, 8>(p, st);
+        default: return launch_cfg<64, 64, 2, 2, 32, 0, 1>(p, st);     // 28
     }
 }

@@ -35,6 +35,8 @@ struct ConvParams {
     int split_target;      // >0: split K until the grid has about this many blocks (autotuner)
     float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]
     unsigned x_bytes, y_bytes, y2_bytes, res_bytes;   // extents of the views (buffer-resource bounds)
+    unsigned w_bytes;      // bytes of one weight class
+    const int4* ktab;      // per K step (and parity class): {dy, dx, input byte offset, 0}; null -> generic path
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
