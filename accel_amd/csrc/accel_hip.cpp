@@ -357,7 +357,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,4,4)", wname.c_str(), cin, cout);
         c.kh = c.kw = 2; c.sh = c.sw = 1; c.dh = c.dw = 1; c.ph = c.pw = 0;
         c.Cin = cin_pad;
-        c.K_pad = roundup(4 * cin_pad, 32);
+        c.K_pad = roundup(4 * cin_pad, 64);
         pack_deconv2x_w(*w, cin_pad, rows, c.K_pad, packed);
         c.deconv2x = 1;
         c.w_class_stride = (size_t)rows * c.K_pad;
@@ -372,7 +372,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,%d,%d) got (%ld,%ld,%ld,%ld)",
                         wname.c_str(), cout, cin, wkh, wkw, (long)w->shape[0], (long)w->shape[1], (long)w->shape[2], (long)w->shape[3]);
         const int Kreal = wkh * wkw * cin_pad;
-        c.K_pad = roundup(Kreal, 32);
+        c.K_pad = roundup(Kreal, 64);
         pack_conv_w(*w, cin_pad, rows, c.K_pad, packed);
         if (cols) { c.kh = c.kw = 1; c.Cin = Kreal; }
         else { c.kh = kh; c.kw = kw; c.Cin = cin_pad; }
@@ -439,15 +439,15 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
     c.w_bytes = (unsigned)((size_t)rows * c.K_pad * sizeof(float));
-    if (c.Cin % 32 == 0) {
-        // tap table for the wave-uniform fast path: K step -> (dy, dx, byte offset relative to tap 0)
-        const int KT = c.K_pad / 32, classes = c.deconv2x ? 4 : 1;
-        std::vector<int> tab((size_t)classes * KT * 4, 0);
+    if (c.Cin % 16 == 0) {
+        // tap table for the wave-uniform fast path: 16-wide K granule -> (dy, dx, byte offset relative to tap 0)
+        const int KT = c.K_pad / 16, classes = c.deconv2x ? 4 : 1;
+        std::vector<int> tab((size_t)classes * (KT + 4) * 4, 0);   // +4 granules: the kernel prefetches one step ahead
         for (int cls = 0; cls < classes; ++cls)
             for (int kt = 0; kt < KT; ++kt) {
-                const int k = kt * 32, tap = k / c.Cin, ci = k % c.Cin;
+                const int k = kt * 16, tap = k / c.Cin, ci = k % c.Cin;
                 const int ky = tap / c.kw, kx = tap % c.kw;
-                int* t = &tab[((size_t)cls * KT + kt) * 4];
+                int* t = &tab[((size_t)cls * (KT + 4) + kt) * 4];
                 if (tap >= c.kh * c.kw) { t[0] = -(1 << 28); t[1] = 0; t[2] = 0; continue; }   // padded K: always out of range
                 t[0] = ky * c.dh; t[1] = kx * c.dw;
                 t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * 4;
@@ -652,7 +652,7 @@ static int autotune_plan(accel_plan* p)
         std::vector<Cand>& cs = cands[i];
         if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
-            static const int tiles[] = {0, 1, 2, 3, 10, 11, 12};   // BK-64 variants (13, 14) need K_pad % 64 == 0: experiments only
+            static const int tiles[] = {0, 1, 2, 3, 10, 11, 12, 13, 15};
             for (int t : tiles) {
                 cs.push_back({t, 0, 0});
                 ConvParams q = c;

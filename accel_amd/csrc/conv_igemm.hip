@@ -136,9 +136,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 4);
 
     f32x4 ra[AR], rb[BR];
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 4) : 0);
+    int4 tk_next = FAST ? ktab[kt_begin * BK / 16] : make_int4(0, 0, 0, 0);   // prefetched one K step ahead (scalar load latency)
     auto load_tiles = [&](int k0) {
         if (FAST) {
-            const int4 tk = p.ktab[(p.deconv2x ? blockIdx.y * KT_all : 0) + k0 / BK];   // {dy, dx, byte offset, 0}
+            const int4 tk = tk_next;                                         // {dy, dx, byte offset, 0}
+            tk_next = ktab[(k0 + BK) / 16];
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
@@ -410,12 +413,14 @@ int conv_pick_tile(const ConvParams& p)
     return 3;
 }
 
+int conv_tile_bk(int tile) { return (tile == 13 || tile == 14) ? 64 : tile == 15 ? 16 : 32; }
+
 static void tile_dims(int tile, int& bm, int& bn)
 {
-    static const int BMs[15] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128};
-    static const int BNs[15] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128};
+    static const int BMs[16] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128};
+    static const int BNs[16] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128};
     if (tile >= 20) tile = (tile == 23 || tile >= 26) ? 3 : 0;
-    if (tile < 0 || tile > 14) tile = 3;
+    if (tile < 0 || tile > 15) tile = 3;
     bm = BMs[tile]; bn = BNs[tile];
 }
 
@@ -430,7 +435,7 @@ size_t conv_plan_split(ConvParams& p)
     tile_dims(tile, bm, bn);
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
-    const int KT = p.K_pad / 32;
+    const int KT = p.K_pad / conv_tile_bk(tile);
     const int min_blocks = p.split_target > 0 ? p.split_target : 256;
     const int target = p.split_target > 0 ? p.split_target : 768;
     const int min_steps = 4;
@@ -464,6 +469,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 12: return launch_cfg<64, 128, 2, 4, 32, 1>(p, st);    // 8 waves, wave tile 32x32
         case 13: return launch_cfg<64, 64, 2, 2, 64, 1>(p, st);     // BK 64
         case 14: return launch_cfg<128, 128, 2, 2, 64, 1>(p, st);   // BK 64
+        case 15: return launch_cfg<128, 128, 2, 2, 16, 0>(p, st);   // BK 16: half the LDS, 4 blocks/CU
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
         case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier
         case 22: return launch_cfg<128, 128, 2, 2, 32, 0, 2>(p, st);   // ablation: no barrier (racy, timing only)
