@@ -53,7 +53,8 @@ extern "C" const char* accel_version(void) { return "accel_hip 0.1 (gfx950)"; }
 // ---------------------------------------------------------------------------
 struct accel_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;     // compute stream (the one callers order against)
+    hipStream_t stream1;    // side stream for the independent branch of two-stream plans
 };
 
 struct HostParam {
@@ -103,6 +104,10 @@ struct Op {
     const float* p1 = nullptr;
     size_t nbytes = 0;
     int H = 0, W = 0;
+    int stream = 0;             // 0 = compute stream, 1 = side stream
+    std::vector<int> waits;     // op indices (on the other stream) this op depends on
+    bool signal = false;        // some op on the other stream waits for this one
+    hipEvent_t done = nullptr;
 };
 
 struct accel_plan {
@@ -117,8 +122,11 @@ struct accel_plan {
     bool finalized = false;
     bool allow_graph = true;
     bool allow_tune = true;
-    size_t ws_bytes = 0;            // split-K workspace shared by the plan's convs (stream-ordered)
+    size_t ws_bytes = 0;            // split-K workspace shared by the convs of one stream (stream-ordered)
     float* ws = nullptr;
+    float* ws1 = nullptr;
+    bool two_streams = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -249,6 +257,13 @@ static int parse_plan(accel_plan* p, const char* text)
         op.kind_name = kind;
         op.kv = kv;
         op.name = kv_str(kv, "name");
+        op.stream = (int)kv_int(kv, "stream", 0);
+        if (op.stream) p->two_streams = true;
+        if (kv_has(kv, "wait")) {
+            std::stringstream ws_(kv_str(kv, "wait"));
+            std::string t;
+            while (std::getline(ws_, t, ',')) op.waits.push_back(atoi(t.c_str()));
+        }
         op.flops = kv_f(kv, "flops");
         op.bytes = kv_f(kv, "bytes");
         if (kind == "prep_rgb") op.kind = OP_PREP_RGB;
@@ -588,9 +603,9 @@ static int finalize_op(accel_plan* p, Op& op)
     return fail(ACCEL_ERR_PLAN, "unhandled op kind");
 }
 
-static int launch_op(accel_plan* p, Op& op)
+static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
 {
-    hipStream_t st = p->m->ctx->stream;
+    hipStream_t st = (op.stream == 1 && !single_stream) ? p->m->ctx->stream1 : p->m->ctx->stream;
     hipError_t e = hipSuccess;
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
@@ -608,11 +623,26 @@ static int launch_op(accel_plan* p, Op& op)
     return 0;
 }
 
+// Issues the plan.  Two-stream plans fork the side stream from the compute stream, order the few
+// cross-stream reads with events, and join at the end -- under stream capture this becomes a graph
+// with two parallel branches, eagerly it is the same thing with real events.
 static int run_eager(accel_plan* p)
 {
+    accel_ctx* c = p->m->ctx;
+    if (p->two_streams) {
+        HIP_TRY(hipEventRecord(p->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream1, p->ev_fork, 0));
+    }
     for (Op& op : p->ops) {
+        hipStream_t st = op.stream == 1 ? c->stream1 : c->stream;
+        for (int j : op.waits) HIP_TRY(hipStreamWaitEvent(st, p->ops[j].done, 0));
         int rc = launch_op(p, op);
         if (rc) return rc;
+        if (op.signal) HIP_TRY(hipEventRecord(op.done, st));
+    }
+    if (p->two_streams) {
+        HIP_TRY(hipEventRecord(p->ev_join, c->stream1));
+        HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_join, 0));
     }
     return 0;
 }
@@ -668,8 +698,9 @@ static int autotune_plan(accel_plan* p)
         float* nw = nullptr;
         HIP_TRY(hipMalloc((void**)&nw, ws_need));
         p->owned.push_back(nw);
-        p->ws = nw; p->ws_bytes = ws_need;
-        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = nw;
+        p->ws = p->ws1 = nw; p->ws_bytes = ws_need;
+        if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, ws_need)); p->owned.push_back(p->ws1); }
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
     }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -721,6 +752,7 @@ extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
     accel_ctx* c = new accel_ctx();
     c->device = device_id;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream1, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(ACCEL_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     *out = c;
     return 0;
@@ -730,7 +762,9 @@ extern "C" int accel_ctx_destroy(accel_ctx* ctx)
 {
     if (!ctx) return 0;
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->stream1);
     hipStreamDestroy(ctx->stream);
+    hipStreamDestroy(ctx->stream1);
     delete ctx;
     return 0;
 }
@@ -755,6 +789,9 @@ extern "C" int accel_model_create(accel_ctx* ctx, accel_model** out)
 
 static void plan_free(accel_plan* p)
 {
+    for (Op& op : p->ops) if (op.done) hipEventDestroy(op.done);
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->gexec) hipGraphExecDestroy(p->gexec);
     if (p->graph) hipGraphDestroy(p->graph);
     for (void* d : p->owned) hipFree(d);
@@ -816,10 +853,23 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         int rc = finalize_op(p, op);
         if (rc) return rc;
     }
+    if (p->two_streams) {
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        for (Op& op : p->ops)
+            for (int j : op.waits) {
+                if (j < 0 || j >= (int)p->ops.size()) return fail(ACCEL_ERR_PLAN, "wait=%d out of range", j);
+                Op& prod = p->ops[j];
+                if (!prod.done) HIP_TRY(hipEventCreateWithFlags(&prod.done, hipEventDisableTiming));
+                prod.signal = true;
+            }
+    }
     if (p->ws_bytes) {
         HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
         p->owned.push_back(p->ws);
-        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = p->ws;
+        p->ws1 = p->ws;
+        if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, p->ws_bytes)); p->owned.push_back(p->ws1); }
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
     }
     HIP_TRY(hipDeviceSynchronize());
     if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
@@ -877,7 +927,7 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
     for (int it = 0; it < iters && !rc; ++it) {
         for (size_t i = 0; i < n && !rc; ++i) {
             HIP_TRY(hipEventRecord(ev[2 * i], st));
-            rc = launch_op(p, p->ops[i]);
+            rc = launch_op(p, p->ops[i], true);
             HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
         }
         HIP_TRY(hipStreamSynchronize(st));

@@ -42,6 +42,7 @@ class VBuf(object):
         self.id, self.Cs, self.H, self.W, self.space = bid, Cs, H, W, space
         self.first, self.last = None, None
         self.off = 0
+        self.streams = set()
 
     @property
     def nbytes(self):
@@ -71,7 +72,7 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, keep_feat_nchw=False):
+    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True):
         self.sym = sym
         self.shapes = infer_shapes(sym, input_shapes)
         self.nodes = sym.topo()
@@ -92,6 +93,24 @@ class Lowering(object):
                 if n.op == "Crop" and idx == 1:
                     continue   # shape reference only
                 self.cons.setdefault(id(i), []).append(n)
+        # variable dependencies of every node: ops that need only `data` (the per-frame correction
+        # branch) are independent of FlowNet / warp / L head until the fusion and go to a second stream
+        self.deps = {}
+        for n in self.nodes:
+            if n.op == "null":
+                self.deps[id(n)] = frozenset([n.name]) if n.name in ("data", "data_key", "feat_key") else frozenset()
+            else:
+                d = frozenset()
+                for idx, i in enumerate(n.inputs):
+                    if n.op == "Crop" and idx == 1:
+                        continue
+                    d |= self.deps.get(id(i), frozenset())
+                self.deps[id(n)] = d
+        compute = [n for n in self.nodes if n.op in ("Convolution", "Deconvolution", "DeformableConvolution")]
+        only_data = [n for n in compute if self.deps[id(n)] == frozenset(["data"])]
+        self.two_streams = bool(multi_stream) and 0 < len(only_data) < len(compute)
+        self.cur_stream = 0
+        self.last_writer = {}   # buffer key -> (op index, stream)
         data_shape = input_shapes["data"]
         self.H, self.W = int(data_shape[2]), int(data_shape[3])
         for name in ("data", "data_key"):
@@ -124,12 +143,34 @@ class Lowering(object):
             return self.pbuf_view("feat", C, H, W)
         return View(self.new_buf(C, H, W), C)
 
+    @staticmethod
+    def _bkey(v):
+        return ("A", v.buf.id) if v.buf.space == "A" else ("P", v.buf.space)
+
     def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0):
         idx = len(self.ops)
         for v in list(reads) + list(writes):
             if v is not None and v.buf.space == "A":
                 v.buf.touch(idx)
         args = dict(args)
+        st = self.cur_stream if self.two_streams else 0
+        for v in list(reads) + list(writes):
+            if v is not None:
+                v.buf.streams.add(st)
+        waits = set()
+        for v in reads:
+            if v is None:
+                continue
+            w = self.last_writer.get(self._bkey(v))
+            if w is not None and w[1] != st:
+                waits.add(w[0])
+        for v in writes:
+            if v is not None:
+                self.last_writer[self._bkey(v)] = (idx, st)
+        if self.two_streams:
+            args["stream"] = st
+            if waits:
+                args["wait"] = ",".join(str(w) for w in sorted(waits))
         if flops:
             args["flops"] = "%.6g" % flops
             self.total_flops += flops
@@ -450,6 +491,7 @@ class Lowering(object):
             if id(n) in self.absorbed or n.op in ("null", "_group"):
                 continue
             op = n.op
+            self.cur_stream = 1 if self.deps.get(id(n)) == frozenset(["data"]) else 0
             if op == "Deconvolution" and self._is_upsampler(n):
                 continue
             if op == "Crop" and self._is_upsampler(n.inputs[0]):
@@ -489,23 +531,36 @@ class Lowering(object):
         return self
 
     def assign_offsets(self):
-        """Greedy first-fit arena packing over [first, last] op-index lifetimes."""
+        """Greedy first-fit arena packing over [first, last] op-index lifetimes.
+
+        Op-list order is the execution order only WITHIN a stream: the side stream forks at the
+        start of the plan, so its ops overlap in time with every compute-stream op.  Buffers are
+        therefore packed per stream into disjoint arena regions; buffers touched by both streams
+        (join inputs) get private space."""
         live = [b for b in self.bufs if b.first is not None]
-        live.sort(key=lambda b: -b.nbytes)
-        placed = []
-        total = 0
+
+        def pack(bufs, base):
+            placed, total = [], 0
+            for b in sorted(bufs, key=lambda b: -b.nbytes):
+                size = (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
+                taken = sorted((q.off - base, q.off - base + (q.nbytes + ALIGN - 1) // ALIGN * ALIGN) for q in placed
+                               if not (q.last < b.first or b.last < q.first))
+                off = 0
+                for s0, e0 in taken:
+                    if off + size <= s0:
+                        break
+                    off = max(off, e0)
+                b.off = base + off
+                placed.append(b)
+                total = max(total, off + size)
+            return total
+
+        total = pack([b for b in live if b.streams <= {0}], 0)
+        total += pack([b for b in live if b.streams == {1}], total)
         for b in live:
-            size = (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
-            taken = sorted((p.off, p.off + (p.nbytes + ALIGN - 1) // ALIGN * ALIGN) for p in placed
-                           if not (p.last < b.first or b.last < p.first))
-            off = 0
-            for s, e in taken:
-                if off + size <= s:
-                    break
-                off = max(off, e)
-            b.off = off
-            placed.append(b)
-            total = max(total, off + size)
+            if len(b.streams) > 1:
+                b.off = total
+                total += (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
         self.arena_bytes = total
 
     def text(self, graph=True):
@@ -532,6 +587,6 @@ def a_is_1x1(n):
     return a["kernel"] == (1, 1) and a["stride"] == (1, 1) and a["pad"] == (0, 0) and not a["no_bias"]
 
 
-def lower(sym, input_shapes, graph=True):
-    lw = Lowering(sym, input_shapes).run()
+def lower(sym, input_shapes, graph=True, multi_stream=True):
+    lw = Lowering(sym, input_shapes, multi_stream=multi_stream).run()
     return lw.text(graph=graph), lw
