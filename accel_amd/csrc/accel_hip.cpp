@@ -400,6 +400,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             return fail(ACCEL_ERR_PLAN, "conv %s: output %dx%d does not match geometry %dx%d", op.name.c_str(), op.b.H, op.b.W, eh, ew);
         if (c.Cin > op.a.Cs) return fail(ACCEL_ERR_PLAN, "conv %s: input view narrower than Cin", op.name.c_str());
     }
+    packed.resize(packed.size() + 256, 0.f);   // slack: the pipelined kernel prefetches up to two K steps past the end
     void* dw_ = nullptr;
     if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
     c.w = static_cast<const float*>(dw_);
@@ -457,12 +458,12 @@ static int finalize_conv(accel_plan* p, Op& op)
     if (c.Cin % 16 == 0) {
         // tap table for the wave-uniform fast path: 16-wide K granule -> (dy, dx, byte offset relative to tap 0)
         const int KT = c.K_pad / 16, classes = c.deconv2x ? 4 : 1;
-        std::vector<int> tab((size_t)classes * (KT + 4) * 4, 0);   // +4 granules: the kernel prefetches one step ahead
+        std::vector<int> tab((size_t)classes * (KT + 12) * 4, 0);   // slack: the pipelined kernel touches up to two K steps past the end
         for (int cls = 0; cls < classes; ++cls)
             for (int kt = 0; kt < KT; ++kt) {
                 const int k = kt * 16, tap = k / c.Cin, ci = k % c.Cin;
                 const int ky = tap / c.kw, kx = tap % c.kw;
-                int* t = &tab[((size_t)cls * (KT + 4) + kt) * 4];
+                int* t = &tab[((size_t)cls * (KT + 12) + kt) * 4];
                 if (tap >= c.kh * c.kw) { t[0] = -(1 << 28); t[1] = 0; t[2] = 0; continue; }   // padded K: always out of range
                 t[0] = ky * c.dh; t[1] = kx * c.dw;
                 t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * 4;
@@ -680,9 +681,9 @@ static int autotune_plan(accel_plan* p)
         if (op.kind != OP_CONV || op.conv.force_tile >= 0) continue;
         ConvParams c = op.conv;
         std::vector<Cand>& cs = cands[i];
-        if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({3, 0, 0}); }
+        if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
-            static const int tiles[] = {0, 1, 2, 3, 10, 11, 12, 13, 15};
+            static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13};
             for (int t : tiles) {
                 cs.push_back({t, 0, 0});
                 ConvParams q = c;

@@ -63,179 +63,12 @@ __device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, 
     else if (r >= d) { ++q; r -= d; }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0, int FAST = 0>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvParams p)
+// Shared tail of both conv kernels: split-K partial store or the fused epilogue
+// (scale/shift -> +residual -> activation -> store, optional dual output).
+template <int MI, int NI, int WGN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
+                                              int lane, int py, int px, int HoWo)
 {
-    constexpr int LDK = BK + 4;
-    constexpr int NTHR = 64 * WGM * WGN;
-    constexpr int CPR = BK / 4;                     // float4 columns per staged row
-    constexpr int RP = NTHR / CPR;                  // rows staged per pass
-    constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
-    constexpr int AR = BM / RP, BR = BN / RP;       // rows each thread stages
-    static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                    // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-
-    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2);
-    // give each XCD a contiguous run of tiles, N-tiles fastest, so the pixel
-    // tile is re-read from that L2 by its neighbours.
-    const int nblk = p.MT * p.NT;
-    const int bid = blockIdx.x;
-    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int nt = swz % p.NT, mt = swz / p.NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    int kw = p.kw, ph = p.ph, pw = p.pw;
-    const float* wbase = p.w;
-    int py = 0, px = 0;
-    if (p.deconv2x) {
-        py = blockIdx.y >> 1; px = blockIdx.y & 1;
-        ph = 1 - py; pw = 1 - px;
-        wbase += (size_t)blockIdx.y * p.w_class_stride;
-    }
-    const int ntaps = p.kh * kw;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
-
-    // ---- staging coordinates --------------------------------------------------
-    const int srow = tid / CPR, scol = (tid % CPR) * 4;
-    int a_iy0[AR], a_ix0[AR], a_nb[AR];
-    unsigned a_off[AR];                     // FAST: byte offset of (row, tap 0, ci = scol), may wrap below 0 at the border
-    const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + RP * i;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);   // invalid rows fail the bounds test below
-        a_ix0[i] = ox * p.sw - pw;
-        a_nb[i] = n * p.H * p.W;
-        a_off[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs + scol) * 4);
-    }
-    // split-K: blockIdx.z owns K steps [kt_begin, kt_end)
-    const int KT_all = p.K_pad / BK;
-    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
-    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
-    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
-
-    const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
-    const size_t wrow_step = (size_t)RP * p.K_pad;
-    // FAST path (Cin % BK == 0): a K step never straddles two taps, so (dy, dx, byte offset) of the
-    // step is wave-uniform and comes from a host-built table through the scalar unit; weights are
-    // fetched through a buffer resource with the K offset in an SGPR (no per-step vector address math).
-    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(wbase, p.w_bytes);
-    unsigned b_off[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 4);
-
-    f32x4 ra[AR], rb[BR];
-    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 4) : 0);
-    int4 tk_next = FAST ? ktab[kt_begin * BK / 16] : make_int4(0, 0, 0, 0);   // prefetched one K step ahead (scalar load latency)
-    auto load_tiles = [&](int k0) {
-        if (FAST) {
-            const int4 tk = tk_next;                                         // {dy, dx, byte offset, 0}
-            tk_next = ktab[(k0 + BK) / 16];
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                ra[i] = buf_load4(xr, ok ? a_off[i] + (unsigned)tk.z : OOB);
-            }
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 4, 0));
-            return;
-        }
-        int tap, ci, ky, kx;
-        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
-        divmod_small(tap, kw, inv_kw, ky, kx);
-        const int dy = ky * p.dh, dx = kx * p.dw;
-        const bool tap_ok = tap < ntaps;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
-            ra[i] = buf_load4(xr, off);
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            rb[i] = *reinterpret_cast<const f32x4*>(wrow0 + i * wrow_step + k0);
-    };
-    auto store_tiles = [&](int buf) {
-        float* a = As + buf * BM * LDK;
-        float* b = Bs + buf * BN * LDK;
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(a + (srow + RP * i) * LDK + scol) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(b + (srow + RP * i) * LDK + scol) = rb[i];
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    load_tiles(kt_begin * BK);
-    store_tiles(0);
-    __syncthreads();
-
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (ABL & 1) ? false : kt + 1 < kt_end;   // ABL bit0: no global loads / LDS stores in the loop
-        if (more && !(ABL & 8)) load_tiles((kt + 1) * BK);       // ABL bit3: LDS stores of stale registers, no loads
-        const float* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
-        const float* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
-        // register double-buffered fragments: t+1 is read from LDS while t feeds the matrix core
-        f32x4 fa[2][MI], fb[2][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
-#pragma unroll
-        for (int t = 0; t < BK / 8; ++t) {
-            const int c = t & 1, n = c ^ 1;
-            // the other LDS buffer was last read before the previous barrier, so the next tile can
-            // be written into it in the middle of this tile's MFMA burst instead of serialising at the end
-            if (MID && more && t == BK / 16 && !(ABL & 4)) store_tiles(cur ^ 1);
-            if (t + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fa[n][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (t + 1) * 8);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) fb[n][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (t + 1) * 8);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][r], fb[c][j][r], acc[i][j], 0, 0, 0);
-        }
-        if (!MID && more && !(ABL & 4)) store_tiles(cur ^ 1);
-        if (ABL & 4) {                                            // ABL bit2: loads issued and waited for, no LDS stores
-#pragma unroll
-            for (int i = 0; i < AR; ++i) asm volatile("" ::"v"(ra[i]));
-#pragma unroll
-            for (int i = 0; i < BR; ++i) asm volatile("" ::"v"(rb[i]));
-        }
-        if (!(ABL & 2)) __syncthreads();                          // ABL bit1: no barrier
-        if (!(ABL & 1)) cur ^= 1;
-    }
-
     // ---- output coordinates of this lane's 16*MI accumulator rows ------------------
     // C/D layout of the 32x32 MFMA: col = lane & 31 (-> co), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
@@ -315,6 +148,400 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     }
 }
 
+template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0, int FAST = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvParams p)
+{
+    constexpr int LDK = BK + 4;
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int CPR = BK / 4;                     // float4 columns per staged row
+    constexpr int RP = NTHR / CPR;                  // rows staged per pass
+    constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
+    constexpr int AR = BM / RP, BR = BN / RP;       // rows each thread stages
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2);
+    // give each XCD a contiguous run of tiles, N-tiles fastest, so the pixel
+    // tile is re-read from that L2 by its neighbours.
+    const int nblk = p.MT * p.NT;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = swz % p.NT, mt = swz / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    int kw = p.kw, ph = p.ph, pw = p.pw;
+    const float* wbase = p.w;
+    int py = 0, px = 0;
+    if (p.deconv2x) {
+        py = blockIdx.y >> 1; px = blockIdx.y & 1;
+        ph = 1 - py; pw = 1 - px;
+        wbase += (size_t)blockIdx.y * p.w_class_stride;
+    }
+    const int ntaps = p.kh * kw;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+
+    // ---- staging coordinates --------------------------------------------------
+    const int srow = tid / CPR, scol = (tid % CPR) * 4;
+    int a_iy0[AR], a_ix0[AR], a_nb[AR];
+    unsigned a_off[AR];                     // FAST: byte offset of (row, tap 0, ci = scol), may wrap below 0 at the border
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + RP * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);   // invalid rows fail the bounds test below
+        a_ix0[i] = ox * p.sw - pw;
+        a_nb[i] = n * p.H * p.W;
+        a_off[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs + scol) * 4);
+    }
+    // split-K: blockIdx.z owns K steps [kt_begin, kt_end)
+    const int KT_all = p.K_pad / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
+    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
+
+    const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
+    const size_t wrow_step = (size_t)RP * p.K_pad;
+    // FAST path (Cin % BK == 0): a K step never straddles two taps, so (dy, dx, byte offset) of the
+    // step is wave-uniform and comes from a host-built table through the scalar unit; weights are
+    // fetched through a buffer resource with the K offset in an SGPR (no per-step vector address math).
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(wbase, p.w_bytes);
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 4);
+
+    f32x4 ra[AR], rb[BR];
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 12) : 0);
+    int4 tk_next = FAST ? ktab[kt_begin * BK / 16] : make_int4(0, 0, 0, 0);   // prefetched one K step ahead (scalar load latency)
+    auto load_tiles = [&](int k0) {
+        if (FAST) {
+            const int4 tk = tk_next;                                         // {dy, dx, byte offset, 0}
+            tk_next = ktab[(k0 + BK) / 16];
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ra[i] = buf_load4(xr, ok ? a_off[i] + (unsigned)tk.z : OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 4, 0));
+            return;
+        }
+        int tap, ci, ky, kx;
+        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
+        divmod_small(tap, kw, inv_kw, ky, kx);
+        const int dy = ky * p.dh, dx = kx * p.dw;
+        const bool tap_ok = tap < ntaps;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
+            ra[i] = buf_load4(xr, off);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = *reinterpret_cast<const f32x4*>(wrow0 + i * wrow_step + k0);
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * BM * LDK;
+        float* b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(a + (srow + RP * i) * LDK + scol) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<f32x4*>(b + (srow + RP * i) * LDK + scol) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    if (MID == 2) {
+        // Software-pipelined schedule.  Registers hold tile k+1 in flight for a whole K step; it is
+        // written to the other LDS buffer behind the second-to-last fragment step, the (single) barrier
+        // follows, then the global loads of tile k+2 are issued and the first fragments of tile k+1
+        // are read -- all of that under the MFMAs of the last fragment step.  The serial chain
+        // "ds_write -> wait -> barrier -> ds_read -> wait" no longer sits between two MFMA bursts.
+        constexpr int T = BK / 8;
+        f32x4 fa[2][MI], fb[2][NI];
+        auto read_frags = [&](int buf, int t, int idx) {
+            const float* a = As + buf * BM * LDK + (wm * MI * 32 + frow) * LDK + fk + t * 8;
+            const float* b = Bs + buf * BN * LDK + (wn * NI * 32 + frow) * LDK + fk + t * 8;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[idx][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[idx][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+        };
+        auto mfma_step = [&](int idx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx][i][r], fb[idx][j][r], acc[i][j], 0, 0, 0);
+        };
+        const int nk = kt_end - kt_begin;
+        load_tiles(kt_begin * BK);
+        store_tiles(0);
+        __syncthreads();
+        if (nk > 1) load_tiles((kt_begin + 1) * BK);
+        read_frags(0, 0, 0);
+        int cur = 0;
+        for (int k = 0; k < nk; ++k) {
+#pragma unroll
+            for (int t = 0; t < T - 1; ++t) {
+                read_frags(cur, t + 1, (t + 1) & 1);
+                mfma_step(t & 1);
+            }
+            if (FAST) {
+                // branch-free tail (one scheduling region): past-the-end tiles are loaded/stored too --
+                // the tap table and the weight buffer carry slack for two extra K steps -- so the
+                // scheduler can spread the address math, loads and fragment reads between the MFMAs
+                store_tiles(cur ^ 1);
+                __syncthreads();
+                load_tiles((kt_begin + k + 2) * BK);
+                read_frags(cur ^ 1, 0, 0);
+                mfma_step((T - 1) & 1);
+#pragma unroll
+                for (int q = 0; q < MI * NI * 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x006, (AR * 8 + 16) / (MI * NI * 4) + 1, 0);   // some VALU/SALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // 1 DS read
+                }
+            } else {
+                if (k + 1 < nk) store_tiles(cur ^ 1);
+                __syncthreads();
+                if (k + 2 < nk) load_tiles((kt_begin + k + 2) * BK);
+                if (k + 1 < nk) read_frags(cur ^ 1, 0, 0);
+                mfma_step((T - 1) & 1);
+            }
+            cur ^= 1;
+        }
+        conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+        return;
+    }
+
+    load_tiles(kt_begin * BK);
+    store_tiles(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (ABL & 1) ? false : kt + 1 < kt_end;   // ABL bit0: no global loads / LDS stores in the loop
+        if (more && !(ABL & 8)) load_tiles((kt + 1) * BK);       // ABL bit3: LDS stores of stale registers, no loads
+        const float* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
+        const float* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
+        // register double-buffered fragments: t+1 is read from LDS while t feeds the matrix core
+        f32x4 fa[2][MI], fb[2][NI];
+        if (ABL & 16) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }   // experiment: de-phase co-resident blocks
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            const int c = t & 1, n = c ^ 1;
+            // the other LDS buffer was last read before the previous barrier, so the next tile can
+            // be written into it in the middle of this tile's MFMA burst instead of serialising at the end
+            if (MID && more && t == BK / 16 && !(ABL & 4)) store_tiles(cur ^ 1);
+            if (t + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[n][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + (t + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[n][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK + (t + 1) * 8);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][r], fb[c][j][r], acc[i][j], 0, 0, 0);
+        }
+        if (ABL & 16) __builtin_amdgcn_s_setprio(0);
+        if (!MID && more && !(ABL & 4)) store_tiles(cur ^ 1);
+        if (ABL & 4) {                                            // ABL bit2: loads issued and waited for, no LDS stores
+#pragma unroll
+            for (int i = 0; i < AR; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+            for (int i = 0; i < BR; ++i) asm volatile("" ::"v"(rb[i]));
+        }
+        if (!(ABL & 2)) __syncthreads();                          // ABL bit1: no barrier
+        if (!(ABL & 1)) cur ^= 1;
+    }
+
+    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-DMA variant (FAST shapes only: Cin % 32 == 0).
+// Tiles go HBM/L2 -> LDS directly (`buffer_load_dwordx4 ... lds`): no staging VGPRs, no ds_write
+// pass, and an S-deep LDS ring so the loads of K step k+S-1 are in flight while step k computes.
+// One barrier per K step; waits are counted (`vmcnt(L*(S-2))`), never 0 inside the loop.
+// The DMA writes lane-linearly (wave-uniform base + lane*16 B), so the LDS image is unpadded
+// 128-byte rows; bank conflicts are avoided with an XOR swizzle applied on the SOURCE side:
+// physical 16-byte slot s of row r holds logical K-quad c = s ^ ((r >> 1) & 7), and fragment reads
+// use the same XOR (conflict-free for the 16-lane groups of ds_read_b128).
+// Out-of-image taps / ragged rows use out-of-range buffer offsets: the DMA writes zeros.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <int BM, int BN, int WGM, int WGN, int S>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvParams p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtin only type-checks in the device pass; the host needs the stub alone
+    constexpr int BK = 32;
+    constexpr int NW = WGM * WGN;
+    constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
+    constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;      // DMA instructions per wave per stage (8 rows each)
+    constexpr int L = AI + BI;
+    constexpr int STAGE = (BM + BN) * BK;                  // floats per ring stage
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nblk = p.MT * p.NT;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = swz % p.NT, mt = swz / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    int ph = p.ph, pw = p.pw;
+    const float* wbase = p.w;
+    int py = 0, px = 0;
+    if (p.deconv2x) {
+        py = blockIdx.y >> 1; px = blockIdx.y & 1;
+        ph = 1 - py; pw = 1 - px;
+        wbase += (size_t)blockIdx.y * p.w_class_stride;
+    }
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(wbase, p.w_bytes);
+    const int HoWo = p.Ho * p.Wo;
+
+    // DMA lane assignment: instruction q covers tile rows 8q..8q+7; lane -> (row, physical slot)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int a_iy0[AI], a_ix0[AI];
+    unsigned a_off[AI], b_off[BI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int r = (wave * AI + j) * 8 + lrow;
+        const int c = lslot ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[j] = ok ? oy * p.sh - ph : -(1 << 28);
+        a_ix0[j] = ox * p.sw - pw;
+        a_off[j] = (unsigned)((((n * p.H + a_iy0[j]) * p.W + a_ix0[j]) * p.xCs + c * 4) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int r = (wave * BI + j) * 8 + lrow;
+        const int c = lslot ^ ((r >> 1) & 7);
+        b_off[j] = (unsigned)(((size_t)(n0 + r) * p.K_pad + c * 4) * 4);
+    }
+
+    const int KT_all = p.K_pad / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 12) : 0);
+
+    auto issue = [&](int kt, int slot) {      // DMA K step `kt` into ring slot `slot`
+        const int4 tk = ktab[kt * 2];         // {dy, dx, byte offset, 0}
+        const int as = slot * STAGE, bs = as + BM * BK;     // float offsets into the ring (cast straight from smem: AS3)
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            const int iy = a_iy0[j] + tk.x, ix = a_ix0[j] + tk.y;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(smem + as + (wave * AI + j) * 8 * BK), 16,
+                                                     ok ? a_off[j] + (unsigned)tk.z : OOB, 0, 0, 0);
+        }
+        const int koff = kt * BK * 4;
+#pragma unroll
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_, (lds_void_ptr)(smem + bs + (wave * BI + j) * 8 * BK), 16,
+                                                     b_off[j], koff, 0, 0);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // prologue: S-1 stages in flight (past-the-end steps are issued too, as all-zero K: the tap
+    // table marks them out of range and the weight rows beyond K_pad are never read -- guard instead)
+    const int nk = kt_end - kt_begin;
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nk) issue(kt_begin + s, s);
+
+    // fragment addressing: row r = lane&31 (+32*i), logical quad c = 2t + (lane>>5)
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_rowoff[MI], b_rowoff[NI], a_x[MI], b_x[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const int r = (wm * MI + i) * 32 + frow; a_rowoff[i] = r * BK; a_x[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { const int r = (wn * NI + j) * 32 + frow; b_rowoff[j] = BM * BK + r * BK; b_x[j] = (r >> 1) & 7; }
+
+    for (int k = 0; k < nk; ++k) {
+        // my own DMAs of step k have landed once at most (S-2) newer stages are outstanding
+        const int newer = min(S - 2, nk - 1 - k);
+        if (newer >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (S - 2)) : "memory");
+        else if (S > 2 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's step-k data is in LDS; slot (k-1)%S is free
+        if (k + S - 1 < nk) issue(kt_begin + k + S - 1, (k + S - 1) % S);
+        const float* st = smem + (k % S) * STAGE;
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            f32x4 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const f32x4*>(st + a_rowoff[i] + (((2 * t + fh) ^ a_x[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                fb[j] = *reinterpret_cast<const f32x4*>(st + b_rowoff[j] + (((2 * t + fh) ^ b_x[j]) << 2));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+#endif
+}
+
 // Sum the split-K partials and apply the fused epilogue (one float4 of channels per thread).
 __global__ void splitk_reduce_kernel(ConvParams p, int classes)
 {
@@ -390,6 +617,29 @@ static hipError_t launch_cfg2(const ConvParams& p0, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WGM, int WGN, int S>
+static hipError_t launch_dma(const ConvParams& p0, hipStream_t st)
+{
+    ConvParams p = p0;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (p.Cout_store + BN - 1) / BN;
+    constexpr size_t lds = (size_t)S * (BM + BN) * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WGM, WGN, S>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WGM, WGN, S>), grid, dim3(64 * WGM * WGN), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit <= 1) return e;
+    const long total = (long)grid.y * p.M * (p.Cout_store / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, (int)grid.y);
+    return hipGetLastError();
+}
+
 // Tile choice: the chip has 256 CUs; prefer the largest tile that still gives
 // >= ~2 blocks per CU, narrow-N tiles for the 2/19/72-channel layers.
 int conv_pick_tile(const ConvParams& p)
@@ -417,10 +667,10 @@ int conv_tile_bk(int tile) { return (tile == 13 || tile == 14) ? 64 : tile == 15
 
 static void tile_dims(int tile, int& bm, int& bn)
 {
-    static const int BMs[16] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128};
-    static const int BNs[16] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128};
-    if (tile >= 20) tile = (tile == 23 || tile >= 26) ? 3 : 0;
-    if (tile < 0 || tile > 15) tile = 3;
+    static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 128, 64};
+    static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
+    if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
+    if (tile < 0 || tile > 19) tile = 3;
     bm = BMs[tile]; bn = BNs[tile];
 }
 
@@ -451,23 +701,34 @@ size_t conv_plan_split(ConvParams& p)
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
 {
-    // tile ids: t % 5 = geometry {128x128, 128x64, 64x128, 64x64, 128x32}; +5 mid-loop LDS write;
+    // tile ids: 0-4 = geometry {128x128, 128x64, 64x128, 64x64, 128x32} with the plain schedule;
+    // 5-9 the same geometries with the software-pipelined schedule (MID = 2);
     // +10 = 8-wave / BK-64 experiments (same geometry order)
-    switch (conv_pick_tile(p)) {
+    const int tile = conv_pick_tile(p);
+    if (tile >= 16 && tile <= 19) {
+        if (!(p.ktab && p.Cin % 32 == 0)) return hipErrorInvalidValue;   // DMA variants need the wave-uniform tap table
+        switch (tile) {
+            case 16: return launch_dma<128, 128, 2, 4, 3>(p, st);   // 8 waves, 3-stage ring (96 KB)
+            case 17: return launch_dma<64, 64, 2, 2, 3>(p, st);     // 4 waves, 3 stages (48 KB)
+            case 18: return launch_dma<128, 128, 2, 2, 2>(p, st);   // 4 waves, 2 stages (64 KB)
+            default: return launch_dma<64, 64, 2, 2, 4>(p, st);     // 19: 4 stages (64 KB)
+        }
+    }
+    switch (tile) {
         case 0: return launch_cfg<128, 128, 2, 2, 32, 0>(p, st);
         case 1: return launch_cfg<128, 64, 2, 2, 32, 0>(p, st);
         case 2: return launch_cfg<64, 128, 2, 2, 32, 0>(p, st);
         case 3: return launch_cfg<64, 64, 2, 2, 32, 0>(p, st);
         case 4: return launch_cfg<128, 32, 4, 1, 32, 0>(p, st);
-        case 5: return launch_cfg<128, 128, 2, 2, 32, 1>(p, st);
-        case 6: return launch_cfg<128, 64, 2, 2, 32, 1>(p, st);
-        case 7: return launch_cfg<64, 128, 2, 2, 32, 1>(p, st);
-        case 8: return launch_cfg<64, 64, 2, 2, 32, 1>(p, st);
-        case 9: return launch_cfg<128, 32, 4, 1, 32, 1>(p, st);
-        case 10: return launch_cfg<128, 128, 2, 4, 32, 1>(p, st);   // 8 waves, wave tile 64x32
-        case 11: return launch_cfg<128, 64, 4, 2, 32, 1>(p, st);    // 8 waves, wave tile 32x32
-        case 12: return launch_cfg<64, 128, 2, 4, 32, 1>(p, st);    // 8 waves, wave tile 32x32
-        case 13: return launch_cfg<64, 64, 2, 2, 64, 1>(p, st);     // BK 64
+        case 5: return launch_cfg<128, 128, 2, 2, 32, 2>(p, st);
+        case 6: return launch_cfg<128, 64, 2, 2, 32, 2>(p, st);
+        case 7: return launch_cfg<64, 128, 2, 2, 32, 2>(p, st);
+        case 8: return launch_cfg<64, 64, 2, 2, 32, 2>(p, st);
+        case 9: return launch_cfg<128, 32, 4, 1, 32, 2>(p, st);
+        case 10: return launch_cfg<128, 128, 2, 4, 32, 2>(p, st);   // 8 waves, wave tile 64x32
+        case 11: return launch_cfg<128, 64, 4, 2, 32, 2>(p, st);    // 8 waves, wave tile 32x32
+        case 12: return launch_cfg<64, 128, 2, 4, 32, 2>(p, st);    // 8 waves, wave tile 32x32
+        case 13: return launch_cfg<64, 64, 2, 2, 64, 2>(p, st);     // BK 64
         case 14: return launch_cfg<128, 128, 2, 2, 64, 1>(p, st);   // BK 64
         case 15: return launch_cfg<128, 128, 2, 2, 16, 0>(p, st);   // BK 16: half the LDS, 4 blocks/CU
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
@@ -478,6 +739,8 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 25: return launch_cfg<128, 128, 2, 2, 32, 0, 8>(p, st);   // ablation: LDS stores but no loads
         case 26: return launch_cfg<64, 64, 2, 2, 32, 0, 4>(p, st);
         case 27: return launch_cfg<64, 64, 2, 2, 32, 0, 8>(p, st);
-        default: return launch_cfg<64, 64, 2, 2, 32, 0, 1>(p, st);     // 28
+        case 28: return launch_cfg<64, 64, 2, 2, 32, 0, 1>(p, st);
+        case 29: return launch_cfg<128, 128, 2, 2, 32, 0, 16>(p, st);  // setprio experiment
+        default: return launch_cfg<64, 64, 2, 2, 32, 0, 16>(p, st);    // 30
     }
 }

@@ -46,11 +46,25 @@ def test_conv2d_bias(ctx, C, K, H, W, k, s, p, d):
     close(ctx.conv2d(x, w, b, s, p, d), O.conv2d(x, w, b, s, p, d))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+# 0-4: register-staged tiles, plain schedule; 5-9: software-pipelined; 10-12: 8-wave; 13/15: BK 64/16; 16-19: LDS-DMA ring
+ALL_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19]
+
+
+@pytest.mark.parametrize("tile", ALL_TILES)
 def test_conv2d_every_tile_config(ctx, tile):
-    C, K, H, W = 96, 200, 20, 36
+    C, K, H, W = 128, 200, 20, 36
     x, w = rnd(4, 1, C, H, W), rnd(5, K, C, 3, 3, scale=0.05)
     close(ctx.conv2d(x, w, None, 1, 1, 1, tile=tile), O.conv2d(x, w, None, 1, 1, 1))
+
+
+@pytest.mark.parametrize("tile", ALL_TILES)
+def test_conv2d_every_tile_config_strided_dilated_residual(ctx, tile):
+    C, K, H, W = 64, 136, 23, 31          # ragged M and N tiles, borders on every side
+    x, w, res = rnd(40, 1, C, H, W), rnd(41, K, C, 3, 3, scale=0.05), rnd(42, 1, K, 12, 16)
+    ref = O.relu(O.conv2d(x, w, None, 2, 2, 2) + res)
+    close(ctx.conv2d(x, w, None, 2, 2, 2, residual=res, act=1, tile=tile), ref)
+    x1, w1 = rnd(43, 1, 256, 9, 13), rnd(44, 72, 256, 1, 1, scale=0.05)
+    close(ctx.conv2d(x1, w1, None, 1, 0, 1, tile=tile), O.conv2d(x1, w1, None, 1, 0, 1))
 
 
 def test_conv2d_fused_epilogue(ctx):
