@@ -372,7 +372,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,4,4)", wname.c_str(), cin, cout);
         c.kh = c.kw = 2; c.sh = c.sw = 1; c.dh = c.dw = 1; c.ph = c.pw = 0;
         c.Cin = cin_pad;
-        c.K_pad = roundup(4 * cin_pad, 64);
+        c.K_pad = roundup(4 * cin_pad, 32);
         pack_deconv2x_w(*w, cin_pad, rows, c.K_pad, packed);
         c.deconv2x = 1;
         c.w_class_stride = (size_t)rows * c.K_pad;
@@ -387,7 +387,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s: need (%d,%d,%d,%d) got (%ld,%ld,%ld,%ld)",
                         wname.c_str(), cout, cin, wkh, wkw, (long)w->shape[0], (long)w->shape[1], (long)w->shape[2], (long)w->shape[3]);
         const int Kreal = wkh * wkw * cin_pad;
-        c.K_pad = roundup(Kreal, 64);
+        c.K_pad = roundup(Kreal, 32);
         pack_conv_w(*w, cin_pad, rows, c.K_pad, packed);
         if (cols) { c.kh = c.kw = 1; c.Cin = Kreal; }
         else { c.kh = kh; c.kw = kw; c.Cin = cin_pad; }
@@ -685,6 +685,7 @@ static int autotune_plan(accel_plan* p)
         else {
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13};
             for (int t : tiles) {
+                if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 cs.push_back({t, 0, 0});
                 ConvParams q = c;
                 const size_t base = conv_apply(q, t, 0, 0);

@@ -705,6 +705,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // 5-9 the same geometries with the software-pipelined schedule (MID = 2);
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     const int tile = conv_pick_tile(p);
+    if (p.K_pad % conv_tile_bk(tile)) return hipErrorInvalidValue;
     if (tile >= 16 && tile <= 19) {
         if (!(p.ktab && p.Cin % 32 == 0)) return hipErrorInvalidValue;   // DMA variants need the wave-uniform tap table
         switch (tile) {

@@ -81,9 +81,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("ACCEL_BENCH_FORCE_DIST") == "1"   # exercise the RCCL gather path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from accel_amd import demo, dist as adist, runtime
@@ -109,7 +113,7 @@ def main():
 
     gather = None
     gather_note = "none (single GPU)"
-    if world > 1 and a.gather != "none":
+    if (world > 1 or force_dist) and a.gather != "none":
         try:
             if a.gather == "logits":
                 gather = adist.FrameGather(model, model.ctx, "logits", (19, H, W), "f4", local_rank)
