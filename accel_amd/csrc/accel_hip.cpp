@@ -99,6 +99,8 @@ struct Op {
     PoolParams pool;
     DcnColsParams dcn;
     ScoreTailParams tail;
+    ScoreTailParams tail_lowres;   // set when the fusion can run at score resolution (uniform upsampling filter)
+    float* tail_z = nullptr;
     BufRef a, b, c, d;          // generic buffer slots
     const float* p0 = nullptr;  // generic device param slots
     const float* p1 = nullptr;
@@ -473,6 +475,7 @@ static int finalize_conv(accel_plan* p, Op& op)
         c.ktab = static_cast<const int4*>(dt);
     }
     c.force_tile = (int)kv_int(kv, "tile", -1);
+    c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;
     const size_t ws = conv_plan_split(c);
@@ -585,6 +588,24 @@ static int finalize_op(accel_plan* p, Op& op)
             if ((rc = upload_param(p, kv_str(kv, "wr"), wn, &q.wr)) ||
                 (rc = upload_param(p, kv_str(kv, "cw"), (size_t)q.ncls * 2 * q.ncls, &q.cw)) ||
                 (rc = upload_param(p, kv_str(kv, "cb"), (size_t)q.ncls, &q.cb))) return rc;
+            // fast path: both upsampling filters identical for every class (the reference freezes them at
+            // the bilinear init) -> fuse at score resolution, then upsample ncls maps once
+            const HostParam* hl = get_param(p->m, kv_str(kv, "wl"));
+            const HostParam* hr = get_param(p->m, kv_str(kv, "wr"));
+            bool uniform = kv_int(kv, "lowres", 1) != 0;
+            for (int c = 0; c < q.ncls && uniform; ++c)
+                uniform = !memcmp(hl->data.data(), hl->data.data() + (size_t)c * 1024, 4096) &&
+                          !memcmp(hl->data.data(), hr->data.data() + (size_t)c * 1024, 4096);
+            if (uniform) {
+                const int zCs = roundup(q.ncls, 4);
+                void* z = nullptr;
+                std::vector<float> zeros((size_t)q.Hs * q.Ws * zCs, 0.f);
+                if ((rc = dev_upload(p, zeros.data(), zeros.size() * sizeof(float), &z))) return rc;
+                op.tail_z = static_cast<float*>(z);
+                op.tail_lowres = q;
+                op.tail_lowres.left = op.tail_z; op.tail_lowres.lCs = zCs;
+                op.tail_lowres.right = nullptr; op.tail_lowres.wr = nullptr; op.tail_lowres.cw = nullptr;   // cb stays: bias after upsampling
+            }
         }
         return 0;
     }
@@ -615,7 +636,13 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     case OP_POOL: e = launch_pool(op.pool, st); break;
     case OP_WARP: e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W, st); break;
     case OP_DCN_COLS: e = launch_dcn_cols(op.dcn, st); break;
-    case OP_SCORE_TAIL: e = launch_score_tail(op.tail, st); break;
+    case OP_SCORE_TAIL:
+        if (op.tail_z) {
+            e = launch_score_fuse_lowres(op.tail.left, op.tail.lCs, op.tail.right, op.tail.rCs, op.tail.cw, op.tail_z,
+                                         op.tail_lowres.lCs, op.tail.ncls, op.tail.Hs * op.tail.Ws, st);
+            if (e == hipSuccess) e = launch_score_tail(op.tail_lowres, st);
+        } else e = launch_score_tail(op.tail, st);
+        break;
     case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.H * op.a.W, st); break;
     case OP_EXPORT_NCHW: e = launch_nhwc_to_nchw(op.a.ptr, op.a.Cs, op.b.ptr, op.a.C, op.a.H, op.a.W, st); break;
     case OP_IMPORT_NCHW: e = launch_nchw_to_nhwc(op.a.ptr, op.b.ptr, op.b.Cs, op.b.C, op.b.H, op.b.W, st); break;
@@ -678,7 +705,7 @@ static int autotune_plan(accel_plan* p)
     size_t ws_need = p->ws_bytes;
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
-        if (op.kind != OP_CONV || op.conv.force_tile >= 0) continue;
+        if (op.kind != OP_CONV || op.conv.force_tile >= 0 || op.conv.narrow) continue;
         ConvParams c = op.conv;
         std::vector<Cand>& cs = cands[i];
         if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }

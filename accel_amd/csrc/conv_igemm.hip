@@ -679,7 +679,7 @@ static void tile_dims(int tile, int& bm, int& bn)
 size_t conv_plan_split(ConvParams& p)
 {
     p.ksplit = 1; p.kt_per_split = 0;
-    if (p.no_split) return 0;
+    if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
     tile_dims(tile, bm, bn);
@@ -704,6 +704,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // tile ids: 0-4 = geometry {128x128, 128x64, 64x128, 64x64, 128x32} with the plain schedule;
     // 5-9 the same geometries with the software-pipelined schedule (MID = 2);
     // +10 = 8-wave / BK-64 experiments (same geometry order)
+    if (p.narrow) return launch_conv_narrow(p, st);
     const int tile = conv_pick_tile(p);
     if (p.K_pad % conv_tile_bk(tile)) return hipErrorInvalidValue;
     if (tile >= 16 && tile <= 19) {

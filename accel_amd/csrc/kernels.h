@@ -32,6 +32,7 @@ struct ConvParams {
     int ksplit;            // >1: split-K over blockIdx.z, partials in ws, reduce+epilogue kernel follows
     int kt_per_split;
     int no_split;
+    int narrow;            // Cout <= 4 plain conv: wave-per-pixel dot-product kernel instead of the MFMA tile
     int split_target;      // >0: split K until the grid has about this many blocks (autotuner)
     float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]
     unsigned x_bytes, y_bytes, y2_bytes, res_bytes;   // extents of the views (buffer-resource bounds)
@@ -92,3 +93,6 @@ hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st);
 hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st);
 hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st);
+hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st);   // Cout_store == 4, plain conv, no dual output
+hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,
+                                    float* z, int zCs, int ncls, int npix, hipStream_t st);

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NCLS; ++k) out[k] = sl[k];
+        for (int k = 0; k < NCLS; ++k) out[k] = p.cb ? sl[k] + p.cb[k] : sl[k];
     }
     const size_t HW = (size_t)p.H * p.W, o = (size_t)Y * p.W + X;
     int best = 0;
@@ -388,5 +388,92 @@ hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int 
     const int C4 = (C + 3) / 4;
     const long total = (long)HW * C4;
     hipLaunchKernelGGL(copy_view_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sCs, dst, dCs, C4, total);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Narrow-N convolution (Cout <= 4: FlowNet's 2-channel flow predictors).  An MFMA tile would be
+// >= 87 % padding and the layer is pure latency, so: one wavefront per output pixel, lanes stride
+// over the (tap, ci) reduction with 16-byte loads, four dot products per lane, wave reduction
+// through cross-lane shuffles, fused scale/shift (+activation) epilogue, one float4 store.
+// Weights are the same packed [rows][K_pad] matrix the implicit-GEMM kernel uses.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int oy = m / p.Wo, ox = m - oy * p.Wo;
+    const int C4 = p.Cin / 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = 0; ky < p.kh; ++ky) {
+        const int iy = oy * p.sh - p.ph + ky * p.dh;
+        if ((unsigned)iy >= (unsigned)p.H) continue;
+        for (int kx = 0; kx < p.kw; ++kx) {
+            const int ix = ox * p.sw - p.pw + kx * p.dw;
+            if ((unsigned)ix >= (unsigned)p.W) continue;
+            const float4* xp = reinterpret_cast<const float4*>(p.x + ((size_t)iy * p.W + ix) * p.xCs);
+            const float4* wp = reinterpret_cast<const float4*>(p.w + (size_t)(ky * p.kw + kx) * p.Cin);
+            const size_t rs = (size_t)p.K_pad / 4;
+            for (int c = lane; c < C4; c += 64) {
+                const float4 v = xp[c];
+                const float4 w0 = wp[c], w1 = wp[rs + c], w2 = wp[2 * rs + c], w3 = wp[3 * rs + c];
+                a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+                a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+                a2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+                a3 += v.x * w3.x + v.y * w3.y + v.z * w3.z + v.w * w3.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o); a3 += __shfl_xor(a3, o);
+    }
+    if (lane == 0) {
+        float v[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = v[e] * p.scale[e] + p.shift[e];
+            if (p.res) v[e] += p.res[(size_t)m * p.resCs + e];
+            if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+            else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        *reinterpret_cast<float4*>(p.y + (size_t)m * p.yCs) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st)
+{
+    hipLaunchKernelGGL(conv_narrow_kernel, dim3(cdiv(p.M, 4)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// Low-resolution half of the fused score tail when both upsampling kernels are the same
+// class-independent filter (the frozen bilinear init of the reference, accel_18.py:153): the
+// 2*ncls -> ncls `correction` conv commutes with the per-class upsampling, so it runs on the
+// H/16 x W/16 score maps (256x fewer pixels) and only ncls maps are upsampled afterwards.
+__global__ void score_fuse_lowres_kernel(const float* __restrict__ left, int lCs, const float* __restrict__ right, int rCs,
+                                         const float* __restrict__ cw, float* __restrict__ z, int zCs, int ncls, int npix)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * zCs) return;
+    const int k = idx % zCs, pix = idx / zCs;
+    float v = 0.f;
+    if (k < ncls) {
+        const float* w = cw + k * 2 * ncls;
+        const float* l = left + (size_t)pix * lCs;
+        const float* r = right + (size_t)pix * rCs;
+        for (int c = 0; c < ncls; ++c) v += w[c] * l[c];
+        for (int c = 0; c < ncls; ++c) v += w[ncls + c] * r[c];
+    }
+    z[(size_t)pix * zCs + k] = v;
+}
+
+hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,
+                                    float* z, int zCs, int ncls, int npix, hipStream_t st)
+{
+    hipLaunchKernelGGL(score_fuse_lowres_kernel, dim3(cdiv((long)npix * zCs, 256)), dim3(256), 0, st, left, lCs, right, rCs,
+                       cw, z, zCs, ncls, npix);
     return hipGetLastError();
 }
