@@ -16,6 +16,8 @@ Contract kept from the reference:
 Shapes are static per bind; a new (H, W) re-lowers and re-binds like
 MutableModule.forward does on a shape change (module.py:1026-1042).
 """
+import os
+
 import numpy as np
 
 from .. import lower as _lower
@@ -92,7 +94,7 @@ class Predictor(object):
         if not self._params_loaded:
             self._model.set_params(self._arg_params, self._aux_params)
             self._params_loaded = True
-        text, lw = _lower.lower(self._symbol, shapes)
+        text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0")
         role = "%s_%dx%d_%x" % ("key" if self._is_key else "cur", H, W, id(self) & 0xFFFF)
         plan = self._model.add_plan(role, text)
         plan.finalize()

@@ -687,6 +687,40 @@ struct TuneKey {
 };
 struct TuneVal { int tile, split_target, no_split; };
 static std::map<TuneKey, TuneVal> g_tune_cache;
+static bool g_tune_loaded = false;
+
+// Optional persistence (ACCEL_TUNE_CACHE=<file>): lets a profiled run skip the tuning launches.
+static void tune_cache_load()
+{
+    if (g_tune_loaded) return;
+    g_tune_loaded = true;
+    const char* path = getenv("ACCEL_TUNE_CACHE");
+    if (!path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    TuneKey k; TuneVal v;
+    for (;;) {
+        int n = 0;
+        for (int i = 0; i < 16; ++i) n += fscanf(f, "%d", &k.v[i]);
+        n += fscanf(f, "%d %d %d", &v.tile, &v.split_target, &v.no_split);
+        if (n != 19) break;
+        g_tune_cache[k] = v;
+    }
+    fclose(f);
+}
+
+static void tune_cache_save()
+{
+    const char* path = getenv("ACCEL_TUNE_CACHE");
+    if (!path) return;
+    FILE* f = fopen(path, "w");
+    if (!f) return;
+    for (const auto& kv : g_tune_cache) {
+        for (int i = 0; i < 16; ++i) fprintf(f, "%d ", kv.first.v[i]);
+        fprintf(f, "%d %d %d\n", kv.second.tile, kv.second.split_target, kv.second.no_split);
+    }
+    fclose(f);
+}
 
 static size_t conv_apply(ConvParams& c, int tile, int split_target, int no_split)
 {
@@ -699,6 +733,8 @@ static int autotune_plan(accel_plan* p)
     const char* e = getenv("ACCEL_AUTOTUNE");
     if (e && e[0] == '0') return 0;
     hipStream_t st = p->m->ctx->stream;
+    tune_cache_load();
+    bool tuned_any = false;
     struct Cand { int tile, split_target, no_split; };
     // pass 1: workspace large enough for every candidate
     std::vector<std::vector<Cand>> cands(p->ops.size());
@@ -760,10 +796,12 @@ static int autotune_plan(accel_plan* p)
                 if (ms < best) { best = ms; bv = {k.tile, k.split_target, k.no_split}; }
             }
             it = g_tune_cache.insert({key, bv}).first;
+            tuned_any = true;
         }
         conv_apply(c, it->second.tile, it->second.split_target, it->second.no_split);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (tuned_any && !rc) tune_cache_save();
     return rc;
 }
 

@@ -48,7 +48,7 @@ def cpu_baseline(version, interval):
     from accel_amd.config.config import config
     from accel_amd.utils import image, synth
     from oracle import graphs as G
-    h, w = 256, 512
+    h, w = 512, 1024
     arg, aux = synth.model_params(version, h, w, config)
     P = dict(arg)
     P.update(aux)
