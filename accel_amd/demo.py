@@ -77,7 +77,7 @@ class ClipRunner(object):
 
     data_names = ['data', 'data_key', 'feat_key']
 
-    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None):
+    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None, model=None):
         self.version = str(version)
         self.cfg = cfg
         H, W = frame_hw
@@ -87,10 +87,10 @@ class ClipRunner(object):
         provide = [[('data', (1, 3, H, W)), ('data_key', (1, 3, H, W)), ('feat_key', (1, 2048, 1, 1))]]
         self.key_predictor = Predictor(key_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
                                        provide_data=provide, provide_label=[None],
-                                       arg_params=arg_params, aux_params=aux_params)
+                                       arg_params=arg_params, aux_params=aux_params, model=model)
         self.cur_predictor = Predictor(cur_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
                                        provide_data=provide, provide_label=[None],
-                                       arg_params=arg_params, aux_params=aux_params)
+                                       arg_params=arg_params, aux_params=aux_params, model=model)
         self.feat = None
         self.output_key = 'croped_score_output' if self.version == '101' else 'correction_output'
 

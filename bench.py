@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--interval", type=int, default=5)
     ap.add_argument("--gather", default="logits", choices=["logits", "labels", "none"])
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("ACCEL_BENCH_LANES", "1")),
+                    help="independent clip pipelines per GPU (own model, buffers and streams each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -98,46 +100,58 @@ def main():
     config.SCALES[0] = (H, W)
 
     arg, aux = synth.model_params(a.version, H, W, config)
-    model = runtime.Model(runtime.Context(local_rank))
-    tester._MODELS[local_rank] = model
-    runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)])
-    key_plan, _ = runner.key_predictor.plan_for(H, W)
-    cur_plan, _ = runner.cur_predictor.plan_for(H, W)
+    # `lanes` independent clip pipelines per GPU: own model (weights, arena, buffers) and own HIP streams.
+    # Lane l runs its clips rotated by l * interval / lanes frames, so a key frame of one lane overlaps the
+    # non-key frames of the other (clips are independent: SURVEY.md 8e).
+    lanes = []
+    for l in range(max(1, a.lanes)):
+        model = runtime.Model(runtime.Context(local_rank))
+        runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)], model=model)
+        key_plan, _ = runner.key_predictor.plan_for(H, W)
+        cur_plan, _ = runner.cur_predictor.plan_for(H, W)
+        lanes.append({"model": model, "key": key_plan, "cur": cur_plan, "gather": None, "rot": (l * a.interval) // max(1, a.lanes)})
     del arg, aux
+    model, key_plan, cur_plan = lanes[0]["model"], lanes[0]["key"], lanes[0]["cur"]
 
-    # one clip per step, distinct per rank, resident in HBM
+    # one clip per step and lane, distinct per rank, resident in HBM
     frames = synth.make_clip(H, W, a.interval, seed=20260929 + rank)
     dev_frames = [torch.from_numpy(image.transform(f, config.network.PIXEL_MEANS).astype(np.float32)).cuda()
                   for f in frames]
     nbytes = 3 * H * W * 4
 
-    gather = None
     gather_note = "none (single GPU)"
     if (world > 1 or force_dist) and a.gather != "none":
         try:
-            if a.gather == "logits":
-                gather = adist.FrameGather(model, model.ctx, "logits", (19, H, W), "f4", local_rank)
-            else:
-                gather = adist.FrameGather(model, model.ctx, "labels", (H, W), "u1", local_rank)
+            for ln in lanes:
+                if a.gather == "logits":
+                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "logits", (19, H, W), "f4", local_rank)
+                else:
+                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "labels", (H, W), "u1", local_rank)
             gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered" % a.gather
         except Exception as e:   # keep the bench alive; the JSON says what happened
-            gather, gather_note = None, "disabled: %r" % (e,)
+            for ln in lanes:
+                ln["gather"] = None
+            gather_note = "disabled: %r" % (e,)
 
     def step():
-        for t in range(a.interval):
-            model.write_device("data", dev_frames[t].data_ptr(), nbytes)
-            if t % a.interval == 0:
-                key_plan.run()
-            else:
-                model.write_device("data_key", dev_frames[t - 1].data_ptr(), nbytes)
-                cur_plan.run()
-            if gather is not None:
-                gather.submit()
+        for i in range(a.interval):
+            for ln in lanes:
+                t = (i + ln["rot"]) % a.interval
+                m = ln["model"]
+                m.write_device("data", dev_frames[t].data_ptr(), nbytes)
+                if t == 0:
+                    ln["key"].run()
+                else:
+                    m.write_device("data_key", dev_frames[t - 1].data_ptr(), nbytes)
+                    ln["cur"].run()
+                if ln["gather"] is not None:
+                    ln["gather"].submit()
 
     def sync():
-        if gather is not None:
-            gather.drain()
-        model.ctx.sync()
+        for ln in lanes:
+            if ln["gather"] is not None:
+                ln["gather"].drain()
+            ln["model"].ctx.sync()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -161,7 +175,7 @@ def main():
 
     out = None
     if rank == 0:
-        frames_total = world * a.steps * a.interval
+        frames_total = world * a.steps * a.interval * len(lanes)
         value = frames_total / elapsed
         out = {"metric": "frames/sec 1024x2048 Accel-%s kf=%d" % (a.version, a.interval), "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -170,9 +184,9 @@ def main():
                "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80 (includes H2D + label D2H)",
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "Accel-%s (R101-DCN key branch + FlowNet-S warp + R%s correction branch + fused score tail), "
-                                      "%dx%d clips, key-frame interval %d, 1 clip (1 key + %d non-key frames) per GPU per step"
-                                      % (a.version, a.version, H, W, a.interval, a.interval - 1),
-                          "frames_per_step_per_gpu": a.interval, "parallelism": "clip-sharded x%d (weights replicated)" % world,
+                                      "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step"
+                                      % (a.version, a.version, H, W, a.interval, len(lanes), a.interval - 1),
+                          "frames_per_step_per_gpu": a.interval * len(lanes), "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
                           "gather": gather_note, "weights": "seeded random", "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
     if rank == 0 and not a.no_roofline:
         # dominant kernel = conv_igemm_f32 (implicit-GEMM conv on the fp32 matrix cores): HIP-event pair around
