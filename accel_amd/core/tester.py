@@ -56,7 +56,8 @@ class Predictor(object):
         self._aux_params = aux_params or {}
         self._params_loaded = False
         self._plans = {}      # (H, W) -> (role, runtime.Plan, Lowering)
-        self._is_key = "feat_key" in self.output_names or any(n.startswith("res5c_relu") for n in self.output_names)
+        self._is_key = "feat_key" not in symbol.list_arguments() or "feat_key" in self.output_names \
+            or any(n.startswith("res5c_relu") for n in self.output_names)
         shapes = dict(provide_data[0]) if provide_data else {}
         if max_data_shapes:
             for k, v in max_data_shapes[0]:
@@ -68,7 +69,7 @@ class Predictor(object):
     def _check_params(self, lw_sym, input_shapes):
         arg_shapes, _, aux_shapes = lw_sym.infer_shape(**input_shapes)
         for name, shp in zip(lw_sym.list_arguments(), arg_shapes):
-            if name in input_shapes:
+            if name in input_shapes or name.endswith("_label"):
                 continue
             if name not in self._arg_params:
                 raise RuntimeError("%s not initialized" % name)
@@ -90,6 +91,7 @@ class Predictor(object):
             raise ValueError("image size %dx%d: the FlowNet encoder/decoder needs multiples of 128" % (H, W))
         feat_shape = (1, 2048, 1, 1) if self._is_key else (1, 2048, H // 16, W // 16)
         shapes = {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": feat_shape}
+        shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}
         self._check_params(self._symbol, shapes)
         if not self._params_loaded:
             self._model.set_params(self._arg_params, self._aux_params)

@@ -577,6 +577,7 @@ static int finalize_op(accel_plan* p, Op& op)
         ScoreTailParams& q = op.tail;
         memset(&q, 0, sizeof q);
         q.ncls = (int)kv_int(kv, "ncls", 19);
+        q.softmax = (int)kv_int(kv, "softmax", 0);
         q.left = op.a.ptr; q.lCs = op.a.Cs; q.Hs = op.a.H; q.Ws = op.a.W;
         q.H = (int)kv_int(kv, "H"); q.W = (int)kv_int(kv, "W");
         if (q.H != 16 * q.Hs || q.W != 16 * q.Ws) return fail(ACCEL_ERR_PLAN, "score_tail: output must be 16x the score map");

@@ -86,6 +86,7 @@ struct ScoreTailParams {
     float* logits;                   // NCHW ncls x H x W
     unsigned char* labels;           // H x W
     int ncls, Hs, Ws, H, W;
+    int softmax;                     // apply softmax over classes to the written scores (deeplab test symbol)
 };
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
 

@@ -285,6 +285,16 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
 #pragma unroll
         for (int k = 0; k < NCLS; ++k) out[k] = p.cb ? sl[k] + p.cb[k] : sl[k];
     }
+    if (p.softmax) {      // SoftmaxOutput(multi_output=True), inference: softmax over the class axis
+        float mx = out[0];
+#pragma unroll
+        for (int k = 1; k < NCLS; ++k) mx = fmaxf(mx, out[k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) { out[k] = expf(out[k] - mx); sum += out[k]; }
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) out[k] = out[k] / sum;
+    }
     const size_t HW = (size_t)p.H * p.W, o = (size_t)Y * p.W + X;
     int best = 0;
     float bv = out[0];

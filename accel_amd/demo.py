@@ -92,7 +92,7 @@ class ClipRunner(object):
                                        provide_data=provide, provide_label=[None],
                                        arg_params=arg_params, aux_params=aux_params, model=model)
         self.feat = None
-        self.output_key = 'croped_score_output' if self.version == '101' else 'correction_output'
+        self.output_key = 'croped_score_output' if self.version in ('101', 'dff') else 'correction_output'
 
     def step(self, idx, arrays, interval):
         """One frame (demo.py:235-245).  Returns (logits handle, label-map handle)."""

@@ -460,7 +460,7 @@ class Lowering(object):
             raise NotImplementedError("score upsampling must map H/16 x W/16 scores onto the full image")
         return up
 
-    def lower_tail(self, node, crops, corr=None):
+    def lower_tail(self, node, crops, corr=None, softmax=None):
         ups = [self._tail_branch(c) for c in crops]
         if any(u is None for u in ups):
             raise NotImplementedError("unsupported score tail at %s" % node.name)
@@ -479,10 +479,12 @@ class Lowering(object):
             args.update({"right": right, "wr": ups[1].inputs[1].name, "cw": corr.inputs[1].name, "cb": corr.inputs[2].name})
             reads.append(right)
             flops = 2.0 * ncls * 2 * ncls * self.H * self.W
+        if softmax is not None:
+            args["softmax"] = 1      # SoftmaxOutput(multi_output=True) at test time: softmax over the class axis
         self.emit("score_tail", args, reads, [], flops=flops, nbytes=4.0 * ncls * self.H * self.W + self.H * self.W)
-        for n in [node] + list(crops) + ups + ([corr] if corr is not None else []):
+        for n in [node] + list(crops) + ups + ([corr] if corr is not None else []) + ([softmax] if softmax is not None else []):
             self.absorbed.add(id(n))
-        self.outputs[node.name + "_output"] = "logits"
+        self.outputs[(softmax or node).name + "_output"] = "logits"
 
     # ---- driver ---------------------------------------------------------------------------------------
     def run(self):
@@ -495,8 +497,12 @@ class Lowering(object):
             if op == "Deconvolution" and self._is_upsampler(n):
                 continue
             if op == "Crop" and self._is_upsampler(n.inputs[0]):
+                cons = self.consumers(n)
                 if id(n) in self.head_ids:
                     self.lower_tail(n, [n])
+                elif len(cons) == 1 and cons[0].op == "SoftmaxOutput" and id(cons[0]) in self.head_ids \
+                        and cons[0].attrs.get("multi_output"):
+                    self.lower_tail(n, [n], softmax=cons[0])
                 continue
             if op == "Concat":
                 continue   # score concat; handled at the correction conv

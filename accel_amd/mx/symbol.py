@@ -337,7 +337,12 @@ def infer_shapes(sym, known):
             d, g = need(s.inputs[0]), need(s.inputs[1])
             sh[id(s)] = d[:2] + g[2:]
         elif op == "SoftmaxOutput":
-            sh[id(s)] = need(s.inputs[0])
+            d = need(s.inputs[0])
+            if s.attrs.get("multi_output"):
+                setp(s.inputs[1], (d[0],) + tuple(d[2:]))
+            else:
+                setp(s.inputs[1], (d[0],))
+            sh[id(s)] = d
         elif op == "Custom":
             ins = [list(need(i)) for i in s.inputs]
             res = a["prop"].infer_shape(ins)

@@ -89,7 +89,7 @@ def model_params(version, H, W, cfg=None, **kw):
     from .. import symbols
     cfg = cfg or default_cfg
     name = "accel_" + str(version)
-    inst = getattr(getattr(symbols, name), name)()
+    inst = getattr(getattr(symbols, name), name)()     # '18' | '34' | '50' | '101' | 'dff'
     arg, aux = {}, {}
     shp = {"data": (1, 3, H, W), "data_key": (1, 3, H, W)}
     for getter, feat in ((inst.get_key_test_symbol, (1, 2048, 1, 1)),

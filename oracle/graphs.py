@@ -186,6 +186,14 @@ def key_forward(P, data):
     return {"res5c_relu_output": feat, "croped_score_output": score}
 
 
+def deeplab_forward(P, data):
+    """deeplab/symbols/resnet_v1_101_deeplab_dcn.py:786-821 at test time: the key graph's
+    croped_score through SoftmaxOutput(multi_output=True) = softmax over the class axis."""
+    s = key_forward(P, data)["croped_score_output"]
+    e = np.exp(s - s.max(axis=1, keepdims=True), dtype=np.float32)
+    return {"softmax_output": (e / e.sum(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)}
+
+
 def cur_forward(P, version, data, data_key, feat_key):
     """get_cur_test_symbol: accel_18.py:161-239, accel_34.py:161-239,
     accel_50.py:156-228, accel_101.py:144-193."""
@@ -194,6 +202,9 @@ def cur_forward(P, version, data, data_key, feat_key):
     warped = O.flow_warp(feat_key, flow)
     out = {"warping_feat_output": warped, "_flow": flow}
     hw = data.shape[2:]
+    if version == "dff":        # Deep Feature Flow only: propagate, no correction branch
+        out["croped_score_output"] = head(P, warped, hw)
+        return out
     if version == "101":
         cur = resnet_dcn_101(P, data)
         fused = O.conv2d(np.concatenate([warped, cur], axis=1), P["corr_weight"], P["corr_bias"])
@@ -236,7 +247,7 @@ def run_clip(P, version, frames, interval):
         else:
             o = cur_forward(P, version, im, prev, feat)
             feat = o["warping_feat_output"]
-            logits = o["croped_score_output" if version == "101" else "correction_output"]
+            logits = o["croped_score_output" if version in ("101", "dff") else "correction_output"]
         prev = im
         outs.append((logits, O.argmax_c(logits)))
     return outs

@@ -86,3 +86,51 @@ def test_missing_param_raises(demo_cfg):
             demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
     finally:
         tester.release_models()
+
+
+def test_dff_only_clip(demo_cfg):
+    """README row "DFF": key frames + flow propagation, no correction branch."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 128, 256, 3
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("dff", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 3)
+    try:
+        outs = demo.run_clip("dff", demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    _check(outs, G.run_clip(P, "dff", _oracle_frames(frames, demo_cfg), interval), "dff")
+
+
+def test_deeplab_frame_by_frame_baseline(demo_cfg):
+    """deeplab/ test symbol: `data` only, `softmax_output` (key graph + softmax)."""
+    from accel_amd import mx
+    from accel_amd.core import tester
+    from accel_amd.symbols.resnet_v1_101_deeplab_dcn import resnet_v1_101_deeplab_dcn
+    H, W = 128, 256
+    inst = resnet_v1_101_deeplab_dcn()
+    sym = inst.get_symbol(demo_cfg, is_train=False)
+    assert sym.list_outputs() == ["softmax_output"]
+    inst.infer_shape({"data": (1, 3, H, W)})
+    arg, aux = synth.make_params(inst.arg_shape_dict, inst.aux_shape_dict, data_names=("data", "softmax_label"))
+    frame = image.transform(synth.make_clip(H, W, 1)[0], demo_cfg.network.PIXEL_MEANS).astype(np.float32)
+    try:
+        pred = tester.Predictor(sym, ["data"], ["softmax_label"], context=[mx.gpu(0)],
+                                provide_data=[[("data", (1, 3, H, W))]], provide_label=[None],
+                                arg_params=arg, aux_params=aux)
+        out = pred.predict(mx.io.DataBatch(data=[[mx.nd.array(frame)]], label=[], provide_data=[[("data", frame.shape)]]))[0]
+        prob = out["softmax_output"].asnumpy()
+        lab = mx.nd.argmax(out["softmax_output"], axis=1).asnumpy()
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.deeplab_forward(P, frame)["softmax_output"]
+    assert float(np.abs(prob - ref).max()) <= 1e-4          # probabilities are in [0, 1]
+    np.testing.assert_allclose(prob.sum(axis=1), 1.0, atol=1e-5)
+    srt = np.sort(ref, axis=1)
+    safe = ((srt[:, -1] - srt[:, -2]) > 1e-3)[0]
+    np.testing.assert_array_equal(lab[0][safe], np.argmax(ref, axis=1)[0][safe])
