@@ -350,3 +350,38 @@ def test_product_path_never_imports_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"from oracle", bench)]
     assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.find("def cpu_baseline"))
+
+
+# ---- Cityscapes IO / evaluator (lib/dataset/cityscape.py) -----------------------------------------
+def test_cityscape_layout_palette_and_miou(tmp_path):
+    from PIL import Image
+    from accel_amd.dataset.cityscape import CityScape, confusion_matrix, getpallete
+    root = tmp_path / "cityscapes"
+    rng = np.random.default_rng(3)
+    gts = {}
+    for city, seq in (("frankfurt", "000000"), ("lindau", "000001")):
+        (root / "leftImg8bit" / "val" / city).mkdir(parents=True)
+        (root / "gtFine" / "val" / city).mkdir(parents=True)
+        stem = "%s_%s_000019" % (city, seq)
+        Image.fromarray(rng.integers(0, 255, (8, 16, 3)).astype(np.uint8)).save(str(root / "leftImg8bit" / "val" / city / (stem + "_leftImg8bit.png")))
+        gt = rng.integers(0, 19, (8, 16)).astype(np.uint8)
+        gt[0, :4] = 255                                        # ignore label
+        Image.fromarray(gt).save(str(root / "gtFine" / "val" / city / (stem + "_gtFine_trainIds.png")))
+        gts[stem] = gt
+    db = CityScape("leftImg8bit_val", str(tmp_path), str(root), str(tmp_path / "out"))
+    assert db.image_set_index == sorted(gts) and db.num_images == 2
+    rec = db.load_segdb_from_index(db.image_set_index[0])
+    assert (rec["height"], rec["width"]) == (8, 16) and rec["seg_cls_path"].endswith("_gtFine_trainIds.png")
+    pal = getpallete(256)
+    assert tuple(pal[:3]) == (128, 64, 128) and tuple(pal[18 * 3:18 * 3 + 3]) == (119, 11, 32) and pal[19 * 3:].sum() == 0
+    perfect = [np.where(gts[i] == 255, 0, gts[i]) for i in db.image_set_index]
+    info = db.evaluate_segmentations(perfect)
+    present = np.unique(np.concatenate([g[g != 255] for g in gts.values()]))
+    np.testing.assert_allclose(info["IU_array"][present], 1.0)
+    png = Image.open(str(tmp_path / "out" / "results" / "frankfurt" / "frankfurt_000000_000019.png"))
+    assert png.mode == "P" and np.array_equal(np.array(png), perfect[0])
+    wrong = [np.full_like(p, 3) for p in perfect]
+    info = db.evaluate_segmentations(wrong)
+    assert info["IU_array"][3] > 0 and info["IU_array"][[c for c in present if c != 3]].sum() == 0
+    cm = confusion_matrix(np.array([0, 1, 1, 2]), np.array([0, 1, 2, 2]), 3)
+    assert cm.tolist() == [[1, 0, 0], [0, 1, 1], [0, 0, 1]]
