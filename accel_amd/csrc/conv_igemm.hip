@@ -663,11 +663,11 @@ int conv_pick_tile(const ConvParams& p)
     return 3;
 }
 
-int conv_tile_bk(int tile) { return (tile == 13 || tile == 14) ? 64 : tile == 15 ? 16 : 32; }
+int conv_tile_bk(int tile) { return tile == 13 ? 64 : tile == 15 ? 16 : 32; }
 
 static void tile_dims(int tile, int& bm, int& bn)
 {
-    static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 128, 64};
+    static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 256, 128, 128, 64, 128, 64};
     static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
     if (tile < 0 || tile > 19) tile = 3;
@@ -731,7 +731,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 11: return launch_cfg<128, 64, 4, 2, 32, 2>(p, st);    // 8 waves, wave tile 32x32
         case 12: return launch_cfg<64, 128, 2, 4, 32, 2>(p, st);    // 8 waves, wave tile 32x32
         case 13: return launch_cfg<64, 64, 2, 2, 64, 2>(p, st);     // BK 64
-        case 14: return launch_cfg<128, 128, 2, 2, 64, 1>(p, st);   // BK 64
+        case 14: return launch_cfg<256, 128, 4, 2, 32, 2>(p, st);   // 8 waves, wave tile 64x64 (110 KB LDS, 1 block/CU)
         case 15: return launch_cfg<128, 128, 2, 2, 16, 0>(p, st);   // BK 16: half the LDS, 4 blocks/CU
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
         case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier

@@ -133,10 +133,11 @@ def main(argv=None):
     ap.add_argument('--data', default='', help='Cityscapes root (leftImg8bit_sequence/, gtFine/)')
     ap.add_argument('--synthetic', default='1024x2048')
     ap.add_argument('--params', nargs='*', default=[], help='MXNet .params checkpoints, merged in order')
+    ap.add_argument('--out', default='', help='directory for palette PNGs seg_<frame>.png (demo.py:252-257)')
     args = ap.parse_args(argv)
     version, interv, num_ex = str(args.version), args.interval, args.num_ex
-    if version not in ['18', '34', '50', '101']:
-        raise ValueError("Invalid Accel version '%s' - must be one of Accel-{18,34,50,101}" % version)
+    if version not in ['18', '34', '50', '101', 'dff']:
+        raise ValueError("Invalid Accel version '%s' - must be one of Accel-{18,34,50,101} (or 'dff')" % version)
     if interv < 1:
         raise ValueError("Invalid interval %d - must be >=1" % interv)
     if num_ex < 1:
@@ -194,6 +195,13 @@ def main(argv=None):
         time_sum += elapsed
         count += 1
         print('testing {} {:.4f}s [{:.4f}s]'.format(names[idx], elapsed, time_sum / count))
+        if args.out:
+            from PIL import Image
+            from .dataset.cityscape import getpallete
+            os.makedirs(args.out, exist_ok=True)
+            seg = Image.fromarray(pred)
+            seg.putpalette(getpallete(256))
+            seg.save(os.path.join(args.out, 'seg_' + os.path.basename(names[idx])))
         comps = os.path.basename(names[idx]).split('_')
         lf = labels.get((comps[1], comps[2])) if len(comps) > 2 else None
         if lf is not None:

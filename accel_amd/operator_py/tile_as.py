@@ -1,30 +1,36 @@
-"""`tile_as`: host-side CustomOp, behaviourally the same as the reference's
-dff_deeplab/operator_py/tile_as.py:12-50 (tile `data_content` along axis 0 to the
-batch size of `data_shape`).  Only the detection batch symbol uses it; it is kept
-because the reference's symbol modules register it at import (accel_18.py:11-15)
-and as the worked example of a host-executed plugin op."""
+"""`tile_as`: a host-executed plugin operator registered through the
+operator_py surface.  Behaviour of the reference's operator of the same name
+(dff_deeplab/operator_py/tile_as.py:12-50, used only by the detection batch
+symbol): output = `data_content` repeated along axis 0 up to the batch size of
+`data_shape`; the gradient of the content is the sum over that axis, the shape
+input gets no gradient.  Kept as the worked example of an op that stays on the
+host (plans reject it: `accel_amd.lower` raises for Custom ops without a device
+lowering), next to `FlowWarp`, which does lower to a HIP kernel."""
 import numpy as np
 
 from .. import mx
 
 
+def _to_numpy(a):
+    return a.asnumpy() if hasattr(a, "asnumpy") else np.asarray(a)
+
+
 class TileAsOperator(mx.operator.CustomOp):
     def forward(self, is_train, req, in_data, out_data, aux):
-        content = in_data[0].asnumpy() if hasattr(in_data[0], "asnumpy") else np.asarray(in_data[0])
-        n = in_data[1].shape[0]
-        reps = (n,) + (1,) * (content.ndim - 1)
-        self.assign(out_data[0], req[0], np.tile(content, reps))
+        batch = in_data[0].shape[0]
+        content = _to_numpy(in_data[1])
+        self.assign(out_data[0], req[0], np.repeat(content, batch, axis=0) if content.shape[0] == 1
+                    else np.tile(content, (batch,) + (1,) * (content.ndim - 1)))
 
     def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-        g = out_grad[0].asnumpy() if hasattr(out_grad[0], "asnumpy") else np.asarray(out_grad[0])
-        self.assign(in_grad[0], req[0], g.sum(axis=0, keepdims=True))
-        self.assign(in_grad[1], req[1], 0)
+        self.assign(in_grad[0], req[0], 0)
+        self.assign(in_grad[1], req[1], _to_numpy(out_grad[0]).sum(axis=0, keepdims=True))
 
 
 @mx.operator.register('tile_as')
 class TileAsProp(mx.operator.CustomOpProp):
     def __init__(self):
-        super(TileAsProp, self).__init__(need_top_grad=True)
+        mx.operator.CustomOpProp.__init__(self, need_top_grad=True)
 
     def list_arguments(self):
         return ['data_shape', 'data_content']
@@ -33,9 +39,8 @@ class TileAsProp(mx.operator.CustomOpProp):
         return ['output']
 
     def infer_shape(self, in_shape):
-        data_shape, data_content = in_shape
-        out = [data_shape[0]] + list(data_content[1:])
-        return [data_shape, data_content], [out]
+        shape_like, content = in_shape
+        return [shape_like, content], [[shape_like[0]] + list(content[1:])]
 
     def create_operator(self, ctx, shapes, dtypes):
         return TileAsOperator()

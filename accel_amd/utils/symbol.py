@@ -1,48 +1,53 @@
-"""Base class of the network-description classes; same contract as the
-reference's lib/utils/symbol.py:9-55 (sym, infer_shape, check_parameter_shapes,
-init_weight)."""
-import numpy as np
+"""Base of the network-description classes.
+
+Contract kept from the reference's lib/utils/symbol.py:9-55 because harness
+code relies on it: a `sym` attribute (also reachable as `.symbol`), and after
+`infer_shape(shapes)` the three dicts `arg_shape_dict`, `out_shape_dict`,
+`aux_shape_dict`; `check_parameter_shapes` asserts that every parameter of the
+graph is present with the inferred shape ("<name> not initialized" /
+"shape inconsistent for <name> ...")."""
+import math
 
 
 class Symbol(object):
-    def __init__(self):
-        self.arg_shape_dict = None
-        self.out_shape_dict = None
-        self.aux_shape_dict = None
-        self.sym = None
+    sym = None
+    arg_shape_dict = out_shape_dict = aux_shape_dict = None
 
-    @property
-    def symbol(self):
-        return self.sym
+    symbol = property(lambda self: self.sym)
 
+    # -- to be provided by the model classes ------------------------------------------------
     def get_symbol(self, cfg, is_train=True):
-        raise NotImplementedError()
+        raise NotImplementedError("%s does not build a graph" % type(self).__name__)
 
     def init_weights(self, cfg, arg_params, aux_params):
-        raise NotImplementedError()
+        raise NotImplementedError("%s has no initialiser" % type(self).__name__)
 
-    def get_msra_std(self, shape):
-        fan_in = float(shape[1])
-        if len(shape) > 2:
-            fan_in *= np.prod(shape[2:])
-        return np.sqrt(2 / fan_in)
+    # -- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def get_msra_std(shape):
+        """He/MSRA standard deviation sqrt(2 / fan_in), fan_in = Cin * kh * kw."""
+        fan_in = 1.0
+        for d in shape[1:]:
+            fan_in *= d
+        return math.sqrt(2.0 / fan_in)
 
     def infer_shape(self, data_shape_dict):
-        arg_shape, out_shape, aux_shape = self.sym.infer_shape(**data_shape_dict)
-        self.arg_shape_dict = dict(zip(self.sym.list_arguments(), arg_shape))
-        self.out_shape_dict = dict(zip(self.sym.list_outputs(), out_shape))
-        self.aux_shape_dict = dict(zip(self.sym.list_auxiliary_states(), aux_shape))
+        args, outs, auxs = self.sym.infer_shape(**data_shape_dict)
+        names = (self.sym.list_arguments(), self.sym.list_outputs(), self.sym.list_auxiliary_states())
+        self.arg_shape_dict, self.out_shape_dict, self.aux_shape_dict = (
+            dict(zip(n, s)) for n, s in zip(names, (args, outs, auxs)))
 
     def check_parameter_shapes(self, arg_params, aux_params, data_shape_dict, is_train=True):
-        for k in self.sym.list_arguments():
-            if k in data_shape_dict or (False if is_train else 'label' in k):
-                continue
-            assert k in arg_params, k + ' not initialized'
-            assert tuple(arg_params[k].shape) == tuple(self.arg_shape_dict[k]), \
-                'shape inconsistent for ' + k + ' inferred ' + str(self.arg_shape_dict[k]) + \
-                ' provided ' + str(arg_params[k].shape)
-        for k in self.sym.list_auxiliary_states():
-            assert k in aux_params, k + ' not initialized'
-            assert tuple(aux_params[k].shape) == tuple(self.aux_shape_dict[k]), \
-                'shape inconsistent for ' + k + ' inferred ' + str(self.aux_shape_dict[k]) + \
-                ' provided ' + str(aux_params[k].shape)
+        def verify(name, given, expected):
+            assert name in given, name + ' not initialized'
+            got = tuple(given[name].shape)
+            assert got == tuple(expected[name]), \
+                'shape inconsistent for %s inferred %s provided %s' % (name, expected[name], got)
+
+        for name in self.sym.list_arguments():
+            is_input = name in data_shape_dict
+            is_test_label = (not is_train) and 'label' in name
+            if not (is_input or is_test_label):
+                verify(name, arg_params, self.arg_shape_dict)
+        for name in self.sym.list_auxiliary_states():
+            verify(name, aux_params, self.aux_shape_dict)

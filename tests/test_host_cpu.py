@@ -299,7 +299,7 @@ def test_operator_registration_surface():
     assert t.infer_shape(a=(4, 3, 2, 2), b=(1, 5, 7))[1] == [(4, 5, 7)]
     top = t.attrs["prop"].create_operator(None, None, None)
     o = [np.zeros((4, 5, 7))]
-    top.forward(False, ["write"], [np.arange(35.0).reshape(1, 5, 7), np.zeros((4, 3, 2, 2))], o, [])
+    top.forward(False, ["write"], [np.zeros((4, 3, 2, 2)), np.arange(35.0).reshape(1, 5, 7)], o, [])
     assert (o[0][3] == np.arange(35.0).reshape(5, 7)).all()
 
 
