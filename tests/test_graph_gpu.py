@@ -134,3 +134,32 @@ def test_deeplab_frame_by_frame_baseline(demo_cfg):
     srt = np.sort(ref, axis=1)
     safe = ((srt[:, -1] - srt[:, -2]) > 1e-3)[0]
     np.testing.assert_array_equal(lab[0][safe], np.argmax(ref, axis=1)[0][safe])
+
+
+@pytest.mark.parametrize("H,W", [(256, 384), (384, 128)])
+def test_other_aspect_ratios(demo_cfg, H, W):
+    """sizes other than 1:2 (any multiple of 128 binds); key + one non-key frame vs the oracle"""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    demo_cfg.SCALES[0] = (min(H, W), max(H, W))     # (short-side target, long-side cap), lib/utils/image.py:194-205
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip("18", demo_cfg, arg, aux, frames, 2)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    _check(outs, G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), 2), "accel-18 %dx%d" % (H, W))
+
+
+def test_size_not_multiple_of_128_is_rejected(demo_cfg):
+    from accel_amd import demo
+    from accel_amd.core import tester
+    demo_cfg.SCALES[0] = (200, 256)
+    arg, aux = synth.model_params("18", 256, 256, demo_cfg)
+    try:
+        with pytest.raises(ValueError, match="multiples of 128"):
+            demo.ClipRunner("18", demo_cfg, arg, aux, (200, 256))
+    finally:
+        tester.release_models()
