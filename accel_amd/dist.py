@@ -80,13 +80,17 @@ class FrameGather(object):
 
     def submit(self):
         s = self.n & 1
-        if self.work[s] is not None:
-            self.work[s].wait()
         if self.on_cuda:
             with self.torch.cuda.stream(self.stream):
+                # stream-level wait (not a host block): the COMPUTE stream must not refill this staging
+                # slot before the gather issued from it two frames ago has read it
+                if self.work[s] is not None:
+                    self.work[s].wait()
                 self.model.read_device(self.what, self.stage[s].data_ptr(), self.nbytes)
                 self.work[s] = self.dist.gather(self.stage[s], self.recv[s], dst=0, group=self.group, async_op=True)
         else:   # gloo / CPU path (tests)
+            if self.work[s] is not None:
+                self.work[s].wait()
             self.stage[s].copy_(self.torch.from_numpy(self.model.read(self.what, tuple(self.stage[s].shape),
                                                                       np.float32 if self.stage[s].dtype == self.torch.float32 else np.uint8)))
             self.work[s] = self.dist.gather(self.stage[s], self.recv[s], dst=0, group=self.group, async_op=True)
@@ -96,7 +100,11 @@ class FrameGather(object):
     def drain(self):
         for s in (0, 1):
             if self.work[s] is not None:
-                self.work[s].wait()
+                if self.on_cuda:
+                    with self.torch.cuda.stream(self.stream):
+                        self.work[s].wait()
+                else:
+                    self.work[s].wait()
                 self.work[s] = None
         if self.on_cuda:
             self.stream.synchronize()
