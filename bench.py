@@ -69,8 +69,36 @@ def cpu_baseline(version, interval):
                       % (version, h, w, int(scale), t1 - t0, t2 - t1, interval, int(scale))}
 
 
+class _StdoutToStderr(object):
+    """RCCL prints a version banner on the C stdout when a communicator comes up; the driver wants
+    ONE JSON line on stdout, so fd 1 points at stderr while the process group / gathers run."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     a = parse()
+    with _StdoutToStderr():
+        out, finish = _run(a)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    finish()
+
+
+def _run(a):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -208,11 +236,12 @@ def main():
                            "conv_ms_per_clip": round(ms, 3), "all_kernels_ms_per_clip": round(clip_ms, 3)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.version, a.interval)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    def finish():
+        if dist is not None:
+            with _StdoutToStderr():
+                dist.barrier()
+                dist.destroy_process_group()
+    return (out if rank == 0 else None), finish
 
 
 if __name__ == "__main__":
