@@ -96,7 +96,8 @@ class Predictor(object):
         if not self._params_loaded:
             self._model.set_params(self._arg_params, self._aux_params)
             self._params_loaded = True
-        text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0")
+        text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
+                                conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"))
         role = "%s_%dx%d_%x" % ("key" if self._is_key else "cur", H, W, id(self) & 0xFFFF)
         plan = self._model.add_plan(role, text)
         plan.finalize()

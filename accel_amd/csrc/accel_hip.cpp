@@ -124,6 +124,7 @@ struct accel_plan {
     bool finalized = false;
     bool allow_graph = true;
     bool allow_tune = true;
+    bool f16 = false;               // option dtype=f16: convolutions on the fp16 matrix cores
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of one stream (stream-ordered)
     float* ws = nullptr;
     float* ws1 = nullptr;
@@ -238,6 +239,7 @@ static int parse_plan(accel_plan* p, const char* text)
         if (kind == "option") {
             if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0;
             if (kv_has(kv, "tune")) p->allow_tune = kv_int(kv, "tune", 1) != 0;
+            if (kv_has(kv, "dtype")) p->f16 = kv_str(kv, "dtype") == "f16";
             continue;
         }
         if (kind == "arena") { p->arena_bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10); continue; }
@@ -403,8 +405,16 @@ static int finalize_conv(accel_plan* p, Op& op)
         if (c.Cin > op.a.Cs) return fail(ACCEL_ERR_PLAN, "conv %s: input view narrower than Cin", op.name.c_str());
     }
     packed.resize(packed.size() + 256, 0.f);   // slack: the pipelined kernel prefetches up to two K steps past the end
+    // fp16-MFMA mode (plan option dtype=f16): only where a K chunk of 8 never straddles two taps
+    const char* env_dt = getenv("ACCEL_CONV_DTYPE");   // "f16": also for the single-operator entry points
+    const int want_f16 = (int)kv_int(kv, "f16", (p->f16 || (env_dt && !strcmp(env_dt, "f16"))) ? 1 : 0);
+    c.f16 = (want_f16 && c.Cin % 8 == 0 && cout_store > 4) ? 1 : 0;
     void* dw_ = nullptr;
-    if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
+    if (c.f16) {
+        std::vector<_Float16> ph(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
+        if ((rc = dev_upload(p, ph.data(), ph.size() * sizeof(_Float16), &dw_))) return rc;
+    } else if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
     c.w = static_cast<const float*>(dw_);
 
     // epilogue scale / shift
@@ -456,7 +466,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     if (op.d.set) c.res_bytes = extent(op.d, cout_store);
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
-    c.w_bytes = (unsigned)((size_t)rows * c.K_pad * sizeof(float));
+    c.w_bytes = (unsigned)((size_t)rows * c.K_pad * (c.f16 ? 2 : 4));
     if (c.Cin % 16 == 0) {
         // tap table for the wave-uniform fast path: 16-wide K granule -> (dy, dx, byte offset relative to tap 0)
         const int KT = c.K_pad / 16, classes = c.deconv2x ? 4 : 1;
@@ -475,6 +485,7 @@ static int finalize_conv(accel_plan* p, Op& op)
         c.ktab = static_cast<const int4*>(dt);
     }
     c.force_tile = (int)kv_int(kv, "tile", -1);
+    if (c.f16) c.ktab = nullptr;     // the fp16 kernel derives taps per 8-wide chunk itself
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;
@@ -745,11 +756,13 @@ static int autotune_plan(accel_plan* p)
         if (op.kind != OP_CONV || op.conv.force_tile >= 0 || op.conv.narrow) continue;
         ConvParams c = op.conv;
         std::vector<Cand>& cs = cands[i];
-        if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
+        if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
+        else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13};
             for (int t : tiles) {
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
+                if (c.f16 && !(t <= 3 || t == 10)) continue;
                 cs.push_back({t, 0, 0});
                 ConvParams q = c;
                 const size_t base = conv_apply(q, t, 0, 0);
@@ -777,7 +790,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x, c.ph * 16 + c.pw};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16, c.ph * 16 + c.pw};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

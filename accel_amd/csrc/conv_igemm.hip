@@ -542,6 +542,143 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvPara
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// fp16-MFMA variant (BASELINE config 5: "fp16 convs", fp32 accumulate).
+// Activations stay fp32 NHWC in HBM; the loader converts each 8-float K chunk to half while
+// staging it into LDS, weights are pre-packed as half [rows][K_pad].  v_mfma_f32_32x32x16_f16:
+// lane l holds A[i = l&31][k = 8*(l>>5) .. +8] / B[k][j = l&31] as one 16-byte fragment.
+// LDS rows are 32 halves + 8 pad (80 B: conflict-free ds_read_b128).  Needs Cin % 8 == 0 (a chunk
+// never straddles two taps); other layers (RGB stems, ragged concats) run on the fp32 kernel.
+// Same epilogue, same split-K, same software-pipelined schedule as the fp32 kernel.
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f16_kernel(ConvParams p)
+{
+    constexpr int BK = 32, LDK = BK + 8;            // halves
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int CPR = BK / 8, RP = NTHR / CPR;    // 8-wide chunks per row, rows per pass
+    constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
+    constexpr int AR = BM / RP, BR = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    _Float16* As = smem_h;                   // [2][BM][LDK]
+    _Float16* Bs = smem_h + 2 * BM * LDK;    // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nblk = p.MT * p.NT, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = swz % p.NT, mt = swz / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    int kw = p.kw, ph = p.ph, pw = p.pw;
+    const _Float16* wbase = reinterpret_cast<const _Float16*>(p.w);
+    int py = 0, px = 0;
+    if (p.deconv2x) {
+        py = blockIdx.y >> 1; px = blockIdx.y & 1;
+        ph = 1 - py; pw = 1 - px;
+        wbase += (size_t)blockIdx.y * p.w_class_stride;
+    }
+    const int ntaps = p.kh * kw;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(wbase, p.w_bytes);
+    const int HoWo = p.Ho * p.Wo;
+
+    const int srow = tid / CPR, scol = (tid % CPR) * 8;
+    int a_iy0[AR], a_ix0[AR], a_nb[AR];
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + RP * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);
+        a_ix0[i] = ox * p.sw - pw;
+        a_nb[i] = n * p.H * p.W;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 2);
+
+    const int KT_all = p.K_pad / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
+    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
+
+    f16x8 ra[AR], rb[BR];
+    auto load_tiles = [&](int k0) {
+        int tap, ci, ky, kx;
+        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
+        divmod_small(tap, kw, inv_kw, ky, kx);
+        const int dy = ky * p.dh, dx = kx * p.dw;
+        const bool tap_ok = tap < ntaps;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
+            const f32x4 lo = buf_load4(xr, off), hi = buf_load4(xr, ok ? off + 16u : OOB);
+            f16x8 h;
+            h[0] = (_Float16)lo[0]; h[1] = (_Float16)lo[1]; h[2] = (_Float16)lo[2]; h[3] = (_Float16)lo[3];
+            h[4] = (_Float16)hi[0]; h[5] = (_Float16)hi[1]; h[6] = (_Float16)hi[2]; h[7] = (_Float16)hi[3];
+            ra[i] = h;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            rb[i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 2, 0));
+    };
+    auto store_tiles = [&](int buf) {
+        _Float16* a = As + buf * BM * LDK;
+        _Float16* b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) *reinterpret_cast<f16x8*>(a + (srow + RP * i) * LDK + scol) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<f16x8*>(b + (srow + RP * i) * LDK + scol) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int nk = kt_end - kt_begin;
+    load_tiles(kt_begin * BK);
+    store_tiles(0);
+    __syncthreads();
+    if (nk > 1) load_tiles((kt_begin + 1) * BK);
+    int cur = 0;
+    for (int k = 0; k < nk; ++k) {
+        const _Float16* a = As + cur * BM * LDK + (wm * MI * 32 + frow) * LDK + fk;
+        const _Float16* b = Bs + cur * BN * LDK + (wn * NI * 32 + frow) * LDK + fk;
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+            f16x8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f16x8*>(a + i * 32 * LDK + kb * 16);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const f16x8*>(b + j * 32 * LDK + kb * 16);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (k + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+        if (k + 2 < nk) load_tiles((kt_begin + k + 2) * BK);
+        cur ^= 1;
+    }
+    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+}
+
 // Sum the split-K partials and apply the fused epilogue (one float4 of channels per thread).
 __global__ void splitk_reduce_kernel(ConvParams p, int classes)
 {
@@ -640,6 +777,22 @@ static hipError_t launch_dma(const ConvParams& p0, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WGM, int WGN>
+static hipError_t launch_f16(const ConvParams& p0, hipStream_t st)
+{
+    ConvParams p = p0;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (p.Cout_store + BN - 1) / BN;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 40 * sizeof(_Float16);
+    dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit <= 1) return e;
+    const long total = (long)grid.y * p.M * (p.Cout_store / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, (int)grid.y);
+    return hipGetLastError();
+}
+
 // Tile choice: the chip has 256 CUs; prefer the largest tile that still gives
 // >= ~2 blocks per CU, narrow-N tiles for the 2/19/72-channel layers.
 int conv_pick_tile(const ConvParams& p)
@@ -647,7 +800,7 @@ int conv_pick_tile(const ConvParams& p)
     if (p.force_tile >= 0) return p.force_tile;
     const long classes = p.deconv2x ? 4 : 1;
     const int cs = p.Cout_store;
-    if (cs <= 32) return 4;                              // 128x32
+    if (cs <= 32) return p.f16 ? 3 : 4;                  // 128x32 (fp32) / 64x64 (fp16 path has no 32-wide tile)
     auto blocks = [&](int bm, int bn) {
         return classes * ((p.M + bm - 1) / bm) * (long)((cs + bn - 1) / bn);
     };
@@ -705,6 +858,15 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // 5-9 the same geometries with the software-pipelined schedule (MID = 2);
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
+    if (p.f16) {      // fp16-MFMA path: geometry ids 0-4 / 10-12 map onto the same tile shapes
+        switch (conv_pick_tile(p)) {
+            case 0: case 5: return launch_f16<128, 128, 2, 2>(p, st);
+            case 1: case 6: return launch_f16<128, 64, 2, 2>(p, st);
+            case 2: case 7: return launch_f16<64, 128, 2, 2>(p, st);
+            case 10: return launch_f16<128, 128, 2, 4>(p, st);
+            default: return launch_f16<64, 64, 2, 2>(p, st);   // incl. the narrow-N geometries
+        }
+    }
     const int tile = conv_pick_tile(p);
     if (p.K_pad % conv_tile_bk(tile)) return hipErrorInvalidValue;
     if (tile >= 16 && tile <= 19) {

@@ -32,6 +32,7 @@ struct ConvParams {
     int ksplit;            // >1: split-K over blockIdx.z, partials in ws, reduce+epilogue kernel follows
     int kt_per_split;
     int no_split;
+    int f16;               // weights packed as half, loader converts activations: fp16 MFMA, fp32 accumulate
     int narrow;            // Cout <= 4 plain conv: wave-per-pixel dot-product kernel instead of the MFMA tile
     int split_target;      // >0: split K until the grid has about this many blocks (autotuner)
     float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]

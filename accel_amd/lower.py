@@ -569,10 +569,14 @@ class Lowering(object):
                 total += (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
         self.arena_bytes = total
 
-    def text(self, graph=True):
+    def text(self, graph=True, conv_dtype="f32"):
         lines = ["# accel_amd plan: %d ops, arena %.1f MB, %.2f GFLOP" % (len(self.ops), self.arena_bytes / 1e6, self.total_flops / 1e9)]
         if not graph:
             lines.append("option graph=0")
+        if conv_dtype == "f16":
+            lines.append("option dtype=f16")   # convolutions on the fp16 matrix cores (fp32 storage + accumulate)
+        elif conv_dtype != "f32":
+            raise ValueError("conv_dtype must be 'f32' or 'f16'")
         lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
         for name, nbytes in sorted(self.pbufs.items()):
             lines.append("pbuf name=%s bytes=%d" % (name, nbytes))
@@ -593,6 +597,6 @@ def a_is_1x1(n):
     return a["kernel"] == (1, 1) and a["stride"] == (1, 1) and a["pad"] == (0, 0) and not a["no_bias"]
 
 
-def lower(sym, input_shapes, graph=True, multi_stream=True):
+def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32"):
     lw = Lowering(sym, input_shapes, multi_stream=multi_stream).run()
-    return lw.text(graph=graph), lw
+    return lw.text(graph=graph, conv_dtype=conv_dtype), lw

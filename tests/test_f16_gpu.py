@@ -1,0 +1,70 @@
+"""fp16-MFMA convolution mode (BASELINE config 5 "fp16 convs"): fp32 activations in HBM,
+operands rounded to half in the loader, fp32 accumulation.  Tolerance is the half-precision
+operand rounding (2^-11 relative per operand), not the fp32 bar."""
+import os
+
+import numpy as np
+import pytest
+
+from accel_amd.utils import image, synth
+from oracle import graphs as G, ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def f16_mode():
+    os.environ["ACCEL_CONV_DTYPE"] = "f16"
+    yield
+    os.environ.pop("ACCEL_CONV_DTYPE", None)
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def h(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 10])
+@pytest.mark.parametrize("C,K,H,W,k,s,p,d", [(64, 136, 23, 31, 3, 2, 2, 2), (256, 72, 9, 13, 1, 1, 0, 1), (128, 200, 20, 36, 3, 1, 1, 1)])
+def test_conv_f16_matches_half_rounded_operands(ctx, f16_mode, tile, C, K, H, W, k, s, p, d):
+    x, w, b = rnd(1, 1, C, H, W), rnd(2, K, C, k, k, scale=(2.0 / (C * k * k)) ** 0.5), rnd(3, K)
+    got = ctx.conv2d(x, w, b, s, p, d, tile=tile)
+    ref = O.conv2d(h(x), h(w), b, s, p, d)          # exact products of the rounded operands, fp32 sums
+    assert float(np.abs(got - ref).max()) <= 2e-4 * max(1.0, float(np.abs(ref).max()))
+    full = O.conv2d(x, w, b, s, p, d)
+    assert float(np.abs(got - full).max()) <= 5e-3 * max(1.0, float(np.abs(full).max()))
+
+
+def test_deconv_and_dcn_f16(ctx, f16_mode):
+    x, w = rnd(4, 1, 64, 9, 13), rnd(5, 64, 32, 4, 4, scale=0.1)
+    ref = O.deconv2d(h(x), h(w), None, 2, 1)
+    assert float(np.abs(ctx.deconv2d_4x4s2(x, w) - ref).max()) <= 2e-4 * max(1.0, float(np.abs(ref).max()))
+    xd, wd, off = rnd(6, 1, 32, 12, 20), rnd(7, 48, 32, 3, 3, scale=0.06), rnd(8, 1, 72, 12, 20)
+    ref = O.deform_conv2d(xd, off, wd, 1, 2, 2, 4)
+    assert float(np.abs(ctx.deform_conv2d(xd, off, wd, 1, 2, 2, 4) - ref).max()) <= 5e-3 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_clip_f16_close_to_fp32_oracle(demo_cfg, f16_mode):
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 128, 256, 3
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("50", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 3)
+    try:
+        outs = demo.run_clip("50", demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "50", [image.transform(f, demo_cfg.network.PIXEL_MEANS).astype(np.float32) for f in frames], interval)
+    for t, ((lg, lab), (rlg, rlab)) in enumerate(zip(outs, ref)):
+        # ~100 layers of half-rounded operands on random weights: measured max error 4-5 % of the logit
+        # range at the worst pixel, mean error 20x smaller, 0.1-0.2 % of the labels differ
+        scale = max(1.0, float(np.abs(rlg).max()))
+        assert float(np.abs(lg - rlg).max()) <= 0.1 * scale, "frame %d" % t
+        assert float(np.abs(lg - rlg).mean()) <= 1e-2 * scale, "frame %d" % t
+        assert float((lab != rlab[0]).mean()) < 1e-2
