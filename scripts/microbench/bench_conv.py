@@ -1,0 +1,61 @@
+"""Micro-benchmark of the conv kernel on representative Accel layer shapes (ReLU'd random data,
+clocks warmed by a burst of launches before timing).
+
+    python scripts/microbench/bench_conv.py 0,10,3,8        # tile ids, see launch_conv_igemm()
+
+Tile ids 20-30 are the ablation builds of conv_igemm.hip (no global loads / no barrier / loads only /
+LDS stores only) used for the breakdown quoted in DESIGN.md."""
+import sys, numpy as np
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
+from accel_amd import runtime
+SHAPES = [  # name, cin, cout, H, W (input), k, s, p, d, res, mode
+    ("res4_2b 3x3 256-256 @64x128", 256, 256, 64, 128, 3, 1, 1, 1, 0, "conv"),
+    ("res4_2a 1x1 1024-256", 1024, 256, 64, 128, 1, 1, 0, 1, 0, "conv"),
+    ("res4_2c 1x1 256-1024 +res", 256, 1024, 64, 128, 1, 1, 0, 1, 1, "conv"),
+    ("res3_2c 1x1 128-512 +res @128x256", 128, 512, 128, 256, 1, 1, 0, 1, 1, "conv"),
+    ("res2_2c 1x1 64-256 +res @256x512", 64, 256, 256, 512, 1, 1, 0, 1, 1, "conv"),
+    ("res2_2b 3x3 64-64 @256x512", 64, 64, 256, 512, 3, 1, 1, 1, 0, "conv"),
+    ("fc6 1x1 2048-1024", 2048, 1024, 64, 128, 1, 1, 0, 1, 0, "conv"),
+    ("res5_1 1x1 1024-2048", 1024, 2048, 64, 128, 1, 1, 0, 1, 0, "conv"),
+    ("conv1 7x7 3-64 s2 @1024x2048", 3, 64, 1024, 2048, 7, 2, 3, 1, 0, "conv"),
+    ("flow conv2 5x5 64-128 s2 @256x512", 64, 128, 256, 512, 5, 2, 2, 1, 0, "conv"),
+    ("feat_up deconv 512-2048 @32x64", 512, 2048, 32, 64, 4, 2, 1, 1, 0, "deconv2x"),
+    ("r18 3x3 128-128 @128x256", 128, 128, 128, 256, 3, 1, 1, 1, 0, "conv"),
+]
+ctx = runtime.Context(0)
+tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [-1]
+for (name, cin, cout, H, W, k, s, p, d, res, mode) in SHAPES:
+    if mode == "deconv2x":
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1; Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    cp, kp = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    al = lambda b: (b + 255) // 256 * 256
+    o_x = 0; o_y = al(H * W * cp * 4); o_r = o_y + al(Ho * Wo * kp * 4); tot = o_r + al(Ho * Wo * kp * 4)
+    flops = 2.0 * Ho * Wo * cout * cin * k * k if mode == "conv" else 2.0 * H * W * cout * cin * 16
+    line = []
+    for tile in tiles:
+        m = runtime.Model(ctx)
+        rng = np.random.default_rng(0)
+        wshape = (cout, cin, k, k) if mode == "conv" else (cin, cout, 4, 4)
+        m.set_param("w_weight", (rng.standard_normal(wshape) * 0.05).astype(np.float32))
+        t = "option graph=0\narena bytes=%d\npbuf name=x bytes=%d\npbuf name=r bytes=%d\n" % (tot, cin * H * W * 4, cout * Ho * Wo * 4)
+        t += "import_nchw src=x:0:%d:%d:%d:%d dst=A:%d:%d:%d:%d:%d\n" % (cin, cin, H, W, o_x, cin, cp, H, W)
+        t += "import_nchw src=r:0:%d:%d:%d:%d dst=A:%d:%d:%d:%d:%d\n" % (cout, cout, Ho, Wo, o_r, cout, kp, Ho, Wo)
+        t += "conv name=c in=A:%d:%d:%d:%d:%d out=A:%d:%d:%d:%d:%d w=w_weight act=1 cin=%d cout=%d mode=%s tile=%d flops=%g" % (
+            o_x, cin, cp, H, W, o_y, cout, kp, Ho, Wo, cin, cout, mode, tile, flops)
+        if mode == "conv":
+            t += " k=%d,%d s=%d,%d p=%d,%d d=%d,%d" % (k, k, s, s, p, p, d, d)
+        if res:
+            t += " res=A:%d:%d:%d:%d:%d" % (o_r, cout, kp, Ho, Wo)
+        t += "\n"
+        plan = m.add_plan("b", t)
+        m.write("x", np.maximum(rng.standard_normal((cin, H, W)), 0).astype(np.float32))
+        m.write("r", rng.standard_normal((cout, Ho, Wo)).astype(np.float32))
+        plan.finalize()
+        for _ in range(60): plan.run()      # warm the clocks: short isolated launches under-clock
+        ctx.sync()
+        ms = plan.profile(20)[2]
+        line.append("t%d %7.1f us %6.1f TF" % (tile, ms * 1e3, flops / ms / 1e9))
+        m.close()
+    print("%-36s %s" % (name, " | ".join(line)), flush=True)
