@@ -24,7 +24,7 @@ from .. import lower as _lower
 from .. import runtime
 from ..mx.ndarray import DeviceArray
 
-_MODELS = {}   # device id -> shared runtime.Model (key + cur plans of one demo share it)
+_MODELS = {}   # (device id, H, W) -> shared runtime.Model: the key and cur plans of one demo share buffers
 
 
 def _device_id(context):
@@ -32,10 +32,13 @@ def _device_id(context):
     return int(getattr(ctx, "device_id", 0) or 0)
 
 
-def shared_model(device_id):
-    if device_id not in _MODELS:
-        _MODELS[device_id] = runtime.Model(runtime.Context(device_id))
-    return _MODELS[device_id]
+def shared_model(device_id, hw=None):
+    """One model per device and frame size: persistent buffers (`data`, `feat`, `logits`...) are sized
+    at the first bind and baked into captured graphs, so another resolution gets its own model."""
+    key = (device_id,) + tuple(hw or ())
+    if key not in _MODELS:
+        _MODELS[key] = runtime.Model(runtime.Context(device_id))
+    return _MODELS[key]
 
 
 def release_models():
@@ -51,10 +54,11 @@ class Predictor(object):
         self._symbol = symbol
         self._data_names = list(data_names)
         self.output_names = symbol.list_outputs()
-        self._model = model if model is not None else shared_model(_device_id(context))
+        self._explicit_model = model
+        self._device_id = _device_id(context)
+        self._model = model
         self._arg_params = arg_params or {}
         self._aux_params = aux_params or {}
-        self._params_loaded = False
         self._plans = {}      # (H, W) -> (role, runtime.Plan, Lowering)
         self._is_key = "feat_key" not in symbol.list_arguments() or "feat_key" in self.output_names \
             or any(n.startswith("res5c_relu") for n in self.output_names)
@@ -93,15 +97,21 @@ class Predictor(object):
         shapes = {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": feat_shape}
         shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}
         self._check_params(self._symbol, shapes)
-        if not self._params_loaded:
-            self._model.set_params(self._arg_params, self._aux_params)
-            self._params_loaded = True
+        model = self._explicit_model
+        if model is None:
+            model = shared_model(self._device_id, (H, W))
+        loaded = getattr(model, "_loaded_from", set())
+        if id(self._arg_params) not in loaded:
+            model.set_params(self._arg_params, self._aux_params)
+            loaded.add(id(self._arg_params))
+            model._loaded_from = loaded
+        self._model = model
         text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
                                 conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"))
         role = "%s_%dx%d_%x" % ("key" if self._is_key else "cur", H, W, id(self) & 0xFFFF)
-        plan = self._model.add_plan(role, text)
+        plan = model.add_plan(role, text)
         plan.finalize()
-        self._plans[(H, W)] = (plan, lw)
+        self._plans[(H, W)] = (plan, lw, model)
         return self._plans[(H, W)]
 
     # -- forward ---------------------------------------------------------------------------------
@@ -109,8 +119,8 @@ class Predictor(object):
         arrays = dict(zip(self._data_names, data_batch.data[0]))
         data = arrays["data"]
         H, W = tuple(data.shape)[2:]
-        plan, lw = self._bind((H, W))
-        m = self._model
+        plan, lw, m = self._bind((H, W))
+        self._model = m
         m.write("data", _host(arrays["data"]))
         if not self._is_key:
             m.write("data_key", _host(arrays["data_key"]))
@@ -156,7 +166,8 @@ class Predictor(object):
         self._model.write("feat", np.ascontiguousarray(f[0].transpose(1, 2, 0)))
 
     def plan_for(self, H, W):
-        return self._bind((H, W))
+        plan, lw, _ = self._bind((H, W))
+        return plan, lw
 
 
 def _host(a):

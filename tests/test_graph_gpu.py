@@ -163,3 +163,28 @@ def test_size_not_multiple_of_128_is_rejected(demo_cfg):
             demo.ClipRunner("18", demo_cfg, arg, aux, (200, 256))
     finally:
         tester.release_models()
+
+
+def test_two_resolutions_in_one_process(demo_cfg):
+    """a second frame size re-lowers and binds its own model (MutableModule rebinds on a shape change,
+    module.py:1026-1042); results of the first size are unaffected"""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    arg, aux = synth.model_params("18", 128, 256, demo_cfg)
+    try:
+        outs = {}
+        for (H, W) in ((128, 256), (256, 256), (128, 256)):
+            demo_cfg.SCALES[0] = (min(H, W), max(H, W))
+            frames = synth.make_clip(H, W, 2)
+            data = demo.build_batches(frames, demo_cfg)
+            r = outs.setdefault("runner", demo.ClipRunner("18", demo_cfg, arg, aux, (128, 256)))
+            res = []
+            for i in range(2):
+                lg, _ = r.step(i, data[i], 2)
+                res.append(lg.asnumpy().copy())
+            outs.setdefault((H, W), []).append(res)
+        a, b = outs[(128, 256)]
+        np.testing.assert_array_equal(a[1], b[1])
+        assert outs[(256, 256)][0][1].shape == (1, 19, 256, 256)
+    finally:
+        tester.release_models()
