@@ -467,16 +467,18 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
     c.w_bytes = (unsigned)((size_t)rows * c.K_pad * (c.f16 ? 2 : 4));
-    if (c.Cin % 16 == 0) {
-        // tap table for the wave-uniform fast path: 16-wide K granule -> (dy, dx, byte offset relative to tap 0)
-        const int KT = c.K_pad / 16, classes = c.deconv2x ? 4 : 1;
-        std::vector<int> tab((size_t)classes * (KT + 12) * 4, 0);   // slack: the pipelined kernel touches up to two K steps past the end
+    {
+        // tap table, one entry per 4-wide K granule: (dy, dx, input byte offset relative to tap 0 / channel 0).
+        // FAST shapes read it wave-uniformly through the scalar unit, the others per lane; padded K and the
+        // slack entries (the pipelined kernels prefetch up to two K steps past the end) are marked out of range.
+        const int G = c.K_pad / 4, classes = c.deconv2x ? 4 : 1, slack = 48;
+        std::vector<int> tab((size_t)classes * (G + slack) * 4, 0);
         for (int cls = 0; cls < classes; ++cls)
-            for (int kt = 0; kt < KT; ++kt) {
-                const int k = kt * 16, tap = k / c.Cin, ci = k % c.Cin;
+            for (int g = 0; g < G + slack; ++g) {
+                const int k = g * 4, tap = k / c.Cin, ci = k % c.Cin;
                 const int ky = tap / c.kw, kx = tap % c.kw;
-                int* t = &tab[((size_t)cls * (KT + 12) + kt) * 4];
-                if (tap >= c.kh * c.kw) { t[0] = -(1 << 28); t[1] = 0; t[2] = 0; continue; }   // padded K: always out of range
+                int* t = &tab[((size_t)cls * (G + slack) + g) * 4];
+                if (g >= G || tap >= c.kh * c.kw) { t[0] = -(1 << 28); continue; }
                 t[0] = ky * c.dh; t[1] = kx * c.dw;
                 t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * 4;
             }
@@ -485,7 +487,6 @@ static int finalize_conv(accel_plan* p, Op& op)
         c.ktab = static_cast<const int4*>(dt);
     }
     c.force_tile = (int)kv_int(kv, "tile", -1);
-    if (c.f16) c.ktab = nullptr;     // the fp16 kernel derives taps per 8-wide chunk itself
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;

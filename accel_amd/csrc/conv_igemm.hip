@@ -208,7 +208,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     const int KT_all = p.K_pad / BK;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
     const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
-    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
 
     const float* wrow0 = wbase + (size_t)(n0 + srow) * p.K_pad + scol;
     const size_t wrow_step = (size_t)RP * p.K_pad;
@@ -221,12 +220,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
     for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 4);
 
     f32x4 ra[AR], rb[BR];
-    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 12) : 0);
-    int4 tk_next = FAST ? ktab[kt_begin * BK / 16] : make_int4(0, 0, 0, 0);   // prefetched one K step ahead (scalar load latency)
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);   // one entry per 4-wide K granule
+    // prefetched one K step ahead: FAST = wave-uniform entry through the scalar unit, otherwise the lane's own granule
+    int4 tk_next = ktab[(kt_begin * BK + (FAST ? 0 : scol)) / 4];
     auto load_tiles = [&](int k0) {
         if (FAST) {
             const int4 tk = tk_next;                                         // {dy, dx, byte offset, 0}
-            tk_next = ktab[(k0 + BK) / 16];
+            tk_next = ktab[(k0 + BK) / 4];
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
@@ -238,17 +238,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
                 rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 4, 0));
             return;
         }
-        int tap, ci, ky, kx;
-        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
-        divmod_small(tap, kw, inv_kw, ky, kx);
-        const int dy = ky * p.dh, dx = kx * p.dw;
-        const bool tap_ok = tap < ntaps;
+        // generic path (Cin not a multiple of BK: RGB stems, ragged concats): each lane looks its own
+        // 4-wide granule up in the same table (vector load, prefetched one step ahead) -- no divisions
+        const int4 tk = tk_next;
+        tk_next = ktab[(k0 + BK + scol) / 4];
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
-            ra[i] = buf_load4(xr, off);
+            const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            ra[i] = buf_load4(xr, ok ? a_off[i] - scol * 4u + (unsigned)tk.z : OOB);
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i)
@@ -468,10 +466,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_kernel(ConvPara
     const int KT_all = p.K_pad / BK;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
     const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
-    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 16 + 12) : 0);
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
 
     auto issue = [&](int kt, int slot) {      // DMA K step `kt` into ring slot `slot`
-        const int4 tk = ktab[kt * 2];         // {dy, dx, byte offset, 0}
+        const int4 tk = ktab[kt * 8];         // {dy, dx, byte offset, 0}
         const int as = slot * STAGE, bs = as + BM * BK;     // float offsets into the ring (cast straight from smem: AS3)
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
@@ -607,20 +605,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f16_kernel(ConvPara
     const int KT_all = p.K_pad / BK;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
     const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
-    const float inv_cin = 1.0f / (float)p.Cin, inv_kw = 1.0f / (float)kw;
 
     f16x8 ra[AR], rb[BR];
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
+    int4 tk_next = ktab[(kt_begin * BK + scol) / 4];
+    unsigned a_base[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
     auto load_tiles = [&](int k0) {
-        int tap, ci, ky, kx;
-        divmod_small(k0 + scol, p.Cin, inv_cin, tap, ci);
-        divmod_small(tap, kw, inv_kw, ky, kx);
-        const int dy = ky * p.dh, dx = kx * p.dw;
-        const bool tap_ok = tap < ntaps;
+        const int4 tk = tk_next;                 // the lane's own 8-wide chunk = two 4-wide granules of one tap
+        tk_next = ktab[(k0 + BK + scol) / 4];
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)(((a_nb[i] + iy * p.W + ix) * p.xCs + ci) * 4) : OOB;
+            const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
             const f32x4 lo = buf_load4(xr, off), hi = buf_load4(xr, ok ? off + 16u : OOB);
             f16x8 h;
             h[0] = (_Float16)lo[0]; h[1] = (_Float16)lo[1]; h[2] = (_Float16)lo[2]; h[3] = (_Float16)lo[3];
@@ -726,7 +725,7 @@ static hipError_t launch_cfg2(const ConvParams& p0, hipStream_t st);
 template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0>
 static hipError_t launch_cfg(const ConvParams& p0, hipStream_t st)
 {
-    if (p0.ktab && p0.Cin % BK == 0) return launch_cfg2<BM, BN, WGM, WGN, BK, MID, ABL, 1>(p0, st);
+    if (p0.Cin % BK == 0) return launch_cfg2<BM, BN, WGM, WGN, BK, MID, ABL, 1>(p0, st);
     return launch_cfg2<BM, BN, WGM, WGN, BK, MID, ABL, 0>(p0, st);
 }
 
@@ -870,7 +869,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     const int tile = conv_pick_tile(p);
     if (p.K_pad % conv_tile_bk(tile)) return hipErrorInvalidValue;
     if (tile >= 16 && tile <= 19) {
-        if (!(p.ktab && p.Cin % 32 == 0)) return hipErrorInvalidValue;   // DMA variants need the wave-uniform tap table
+        if (p.Cin % 32) return hipErrorInvalidValue;   // DMA variants need wave-uniform taps per K step
         switch (tile) {
             case 16: return launch_dma<128, 128, 2, 4, 3>(p, st);   // 8 waves, 3-stage ring (96 KB)
             case 17: return launch_dma<64, 64, 2, 2, 3>(p, st);     // 4 waves, 3 stages (48 KB)
