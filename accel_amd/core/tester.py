@@ -108,7 +108,9 @@ class Predictor(object):
         self._model = model
         text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
                                 conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"))
-        role = "%s_%dx%d_%x" % ("key" if self._is_key else "cur", H, W, id(self) & 0xFFFF)
+        role = "key" if self._is_key else "cur"      # the roles accel_key_forward / accel_cur_forward look up
+        if role in model.plans:
+            role = "%s_%x" % (role, id(self) & 0xFFFFFF)
         plan = model.add_plan(role, text)
         plan.finalize()
         self._plans[(H, W)] = (plan, lw, model)

@@ -74,6 +74,7 @@ struct accel_model {
     std::map<std::string, DevBuf> pbufs;
     std::vector<accel_plan*> plans;
     std::map<std::string, accel_plan*> roles;
+    int feat_c = 0, feat_h = 0, feat_w = 0;     // shape of the propagated feature (`meta` line of the plans)
 };
 
 struct BufRef {
@@ -240,6 +241,10 @@ static int parse_plan(accel_plan* p, const char* text)
             if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0;
             if (kv_has(kv, "tune")) p->allow_tune = kv_int(kv, "tune", 1) != 0;
             if (kv_has(kv, "dtype")) p->f16 = kv_str(kv, "dtype") == "f16";
+            continue;
+        }
+        if (kind == "meta") {
+            if (kv_has(kv, "feat_c")) { p->m->feat_c = (int)kv_int(kv, "feat_c"); p->m->feat_h = (int)kv_int(kv, "feat_h"); p->m->feat_w = (int)kv_int(kv, "feat_w"); }
             continue;
         }
         if (kind == "arena") { p->arena_bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10); continue; }
@@ -1066,10 +1071,19 @@ static int frame_outputs(accel_model* m, float* feat_out, float* logits_out, uin
 {
     int rc;
     if (feat_out) {
-        // `feat` lives NHWC in HBM; the plan's optional export op fills `feat_nchw` only when present
-        auto it = m->pbufs.find("feat_nchw");
-        if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "feat_out requested but the plans carry no feat_nchw export");
-        if ((rc = accel_model_read(m, "feat_nchw", feat_out, it->second.bytes, on_dev))) return rc;
+        // `feat` lives NHWC in HBM; the boundary layout is NCHW (res5c_relu_output / warping_feat_output)
+        auto src = m->pbufs.find("feat");
+        if (src == m->pbufs.end() || !m->feat_c) return fail(ACCEL_ERR_ARG, "feat_out requested but the model has no propagated feature");
+        const size_t bytes = (size_t)m->feat_c * m->feat_h * m->feat_w * sizeof(float);
+        DevBuf& tmp = m->pbufs["feat_nchw"];
+        if (!tmp.ptr) {
+            if (hipMalloc(&tmp.ptr, bytes) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipMalloc(feat_nchw) failed");
+            tmp.bytes = bytes;
+        }
+        hipError_t e = launch_nhwc_to_nchw(static_cast<const float*>(src->second.ptr), m->feat_c, static_cast<float*>(tmp.ptr),
+                                           m->feat_c, m->feat_h, m->feat_w, m->ctx->stream);
+        if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "feature export failed: %s", hipGetErrorString(e));
+        if ((rc = accel_model_read(m, "feat_nchw", feat_out, bytes, on_dev))) return rc;
     }
     if (logits_out && (rc = accel_model_read(m, "logits", logits_out, pbuf_bytes(m, "logits"), on_dev))) return rc;
     if (labels_out && (rc = accel_model_read(m, "labels", labels_out, pbuf_bytes(m, "labels"), on_dev))) return rc;

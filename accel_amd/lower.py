@@ -577,6 +577,7 @@ class Lowering(object):
             lines.append("option dtype=f16")   # convolutions on the fp16 matrix cores (fp32 storage + accumulate)
         elif conv_dtype != "f32":
             raise ValueError("conv_dtype must be 'f32' or 'f16'")
+        lines.append("meta feat_c=2048 feat_h=%d feat_w=%d" % (self.H // 16, self.W // 16))
         lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
         for name, nbytes in sorted(self.pbufs.items()):
             lines.append("pbuf name=%s bytes=%d" % (name, nbytes))

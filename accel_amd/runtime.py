@@ -279,14 +279,28 @@ class Model(object):
         check(lib().accel_model_buffer(self.handle, buf.encode(), ctypes.byref(ptr), ctypes.byref(n)))
         return ptr.value, n.value
 
-    def key_forward(self, img=None):
-        check(lib().accel_key_forward(self.handle, None if img is None else _fp(_f32(img)), 0, None, None, None, 0))
+    def _outs(self, want, H, W, ncls=19):
+        feat = np.empty((1, 2048, H // 16, W // 16), np.float32) if "feat" in want else None
+        logits = np.empty((1, ncls, H, W), np.float32) if "logits" in want else None
+        labels = np.empty((1, H, W), np.uint8) if "labels" in want else None
+        return feat, logits, labels
 
-    def cur_forward(self, img_cur=None, img_prev=None):
-        a = None if img_cur is None else _f32(img_cur)
-        b = None if img_prev is None else _f32(img_prev)
-        check(lib().accel_cur_forward(self.handle, None if a is None else _fp(a), None if b is None else _fp(b),
-                                      0, None, None, None, 0))
+    def key_forward(self, img, want=("logits", "labels")):
+        """accel_key_forward: host image in, requested host outputs back (dict)."""
+        img = _f32(img)
+        H, W = img.shape[-2:]
+        f, lg, lb = self._outs(want, H, W)
+        check(lib().accel_key_forward(self.handle, _fp(img), 0, None if f is None else _fp(f), None if lg is None else _fp(lg),
+                                      None if lb is None else _fp(lb), 0))
+        return {k: v for k, v in (("feat", f), ("logits", lg), ("labels", lb)) if v is not None}
+
+    def cur_forward(self, img_cur, img_prev, want=("logits", "labels")):
+        a, b = _f32(img_cur), _f32(img_prev)
+        H, W = a.shape[-2:]
+        f, lg, lb = self._outs(want, H, W)
+        check(lib().accel_cur_forward(self.handle, _fp(a), _fp(b), 0, None if f is None else _fp(f),
+                                      None if lg is None else _fp(lg), None if lb is None else _fp(lb), 0))
+        return {k: v for k, v in (("feat", f), ("logits", lg), ("labels", lb)) if v is not None}
 
     def close(self):
         if self.handle:

@@ -188,3 +188,32 @@ def test_two_resolutions_in_one_process(demo_cfg):
         assert outs[(256, 256)][0][1].shape == (1, 19, 256, 256)
     finally:
         tester.release_models()
+
+
+def test_c_abi_frame_entry_points(demo_cfg):
+    """accel_key_forward / accel_cur_forward (include/accel_hip.h): host buffers in, NCHW feature,
+    logits and uint8 labels out -- same numbers as the Predictor route on the same model."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W = 128, 256
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = _oracle_frames(synth.make_clip(H, W, 2), demo_cfg)
+    data = demo.build_batches(synth.make_clip(H, W, 2), demo_cfg)
+    try:
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        model = r.key_predictor._model
+        lg0, lab0 = r.step(0, data[0], 2)
+        ref_key = (lg0.asnumpy().copy(), lab0.asnumpy().copy(), r.feat.asnumpy().copy())
+        lg1, lab1 = r.step(1, data[1], 2)
+        ref_cur = (lg1.asnumpy().copy(), lab1.asnumpy().copy(), r.feat.asnumpy().copy())
+        k = model.key_forward(frames[0], want=("feat", "logits", "labels"))
+        np.testing.assert_array_equal(k["logits"], ref_key[0])
+        np.testing.assert_array_equal(k["labels"], ref_key[1].astype(np.uint8))
+        np.testing.assert_array_equal(k["feat"], ref_key[2])
+        c = model.cur_forward(frames[1], frames[0], want=("feat", "logits", "labels"))
+        np.testing.assert_array_equal(c["logits"], ref_cur[0])
+        np.testing.assert_array_equal(c["labels"], ref_cur[1].astype(np.uint8))
+        np.testing.assert_array_equal(c["feat"], ref_cur[2])
+    finally:
+        tester.release_models()
