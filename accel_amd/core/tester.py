@@ -107,7 +107,15 @@ class Predictor(object):
             model._loaded_from = loaded
         self._model = model
         text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
-                                conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"))
+                                conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
+                                fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
+        if lw.derived:
+            done = getattr(model, "_derived_from", {})
+            todo = {k: v for k, v in lw.derived.items() if done.get(k) != id(self._arg_params)}
+            for name, w in _lower.fold_params(todo, self._arg_params).items():
+                model.set_param(name, w)
+                done[name] = id(self._arg_params)
+            model._derived_from = done
         role = "key" if self._is_key else "cur"      # the roles accel_key_forward / accel_cur_forward look up
         if role in model.plans:
             role = "%s_%x" % (role, id(self) & 0xFFFFFF)

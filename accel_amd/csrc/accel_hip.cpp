@@ -1002,6 +1002,17 @@ extern "C" int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name
     return 0;
 }
 
+extern "C" int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narrow)
+{
+    if (!p || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_launch: index out of range");
+    const Op& op = p->ops[i];
+    const bool conv = op.kind == OP_CONV;
+    if (tile) *tile = conv ? (op.conv.force_tile >= 0 ? op.conv.force_tile : conv_pick_tile(op.conv)) : -1;
+    if (ksplit) *ksplit = conv ? op.conv.ksplit : 0;
+    if (narrow) *narrow = conv ? op.conv.narrow : 0;
+    return 0;
+}
+
 extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
 {
     if (!p || !p->finalized || !ms || n_ms < (int)p->ops.size() || iters < 1) return fail(ACCEL_ERR_ARG, "accel_plan_profile: bad argument");

@@ -72,8 +72,10 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True):
+    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True, fold_linear=True):
         self.sym = sym
+        self.fold_linear = bool(fold_linear)
+        self.derived = {}      # derived parameter name -> ("deconv4x4s2*conv1x1", deconv weight, conv weight)
         self.shapes = infer_shapes(sym, input_shapes)
         self.nodes = sym.topo()
         self.heads = sym._heads()
@@ -256,6 +258,24 @@ class Lowering(object):
         need_crop = mode == "deconv2x" and a["pad"] == (0, 0)
         cropped = False
         chain = []
+        opname = A.name
+        # linear-linear fold: a bias-free, activation-free 4x4/2 Deconvolution whose only consumer is a 1x1
+        # Convolution (Accel-18/34 `feat_upsampling` -> `fc6`, accel_18.py:196-209) is ONE 4x4/2 deconvolution with
+        # the composed weight  W'[ci,co',ky,kx] = sum_c Wd[ci,c,ky,kx] * Wf[co',c]  -- 3x fewer flops, and the
+        # 2048-channel intermediate is never written.  The composed weight is a derived parameter (fold_params()).
+        if self.fold_linear and mode == "deconv2x" and a["no_bias"] and not need_crop and id(A) not in self.head_ids:
+            cons = self.consumers(A)
+            if len(cons) == 1 and cons[0].op == "Convolution" and cons[0].inputs[0] is A:
+                f = cons[0].attrs
+                if f["kernel"] == (1, 1) and f["stride"] == (1, 1) and f["pad"] == (0, 0) and f["num_group"] == 1:
+                    F = cons[0]
+                    derived = "%s*%s" % (wname, F.inputs[1].name)
+                    self.derived[derived] = ("deconv4x4s2*conv1x1", wname, F.inputs[1].name)
+                    wname = derived
+                    bias = None if f["no_bias"] else F.inputs[2].name
+                    opname = "%s*%s" % (A.name, F.name)
+                    cur = F
+                    chain.append(F)
         while True:
             if id(cur) in self.head_ids:
                 break
@@ -310,7 +330,7 @@ class Lowering(object):
 
         _, cin, hi, wi = self.shape(x)
         _, cout, ho, wo = self.shape(cur)
-        args = {"name": A.name, "out": out, "w": wname, "act": act, "slope": slope, "cin": cin, "cout": cout, "mode": mode}
+        args = {"name": opname, "out": out, "w": wname, "act": act, "slope": slope, "cin": cin, "cout": cout, "mode": mode}
         reads = [res]
         if op == "DeformableConvolution":
             off = A.inputs[1]
@@ -598,6 +618,23 @@ def a_is_1x1(n):
     return a["kernel"] == (1, 1) and a["stride"] == (1, 1) and a["pad"] == (0, 0) and not a["no_bias"]
 
 
-def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32"):
-    lw = Lowering(sym, input_shapes, multi_stream=multi_stream).run()
+def fold_params(derived, params):
+    """Composed weights of the linear-linear folds a Lowering recorded (`Lowering.derived`), computed in float64
+    on the host at bind time -- weight preparation, like the BatchNorm fold.  `params`: name -> array."""
+    import numpy as np
+    out = {}
+    for name, (kind, wd_name, wf_name) in derived.items():
+        if kind != "deconv4x4s2*conv1x1":
+            raise NotImplementedError(kind)
+        wd, wf = params[wd_name], params[wf_name]
+        wd = np.asarray(wd.asnumpy() if hasattr(wd, "asnumpy") else wd, dtype=np.float64)   # (Cin, C, 4, 4)
+        wf = np.asarray(wf.asnumpy() if hasattr(wf, "asnumpy") else wf, dtype=np.float64)   # (Cout, C, 1, 1)
+        cin, c, kh, kw = wd.shape
+        w = wd.transpose(0, 2, 3, 1).reshape(cin * kh * kw, c) @ wf.reshape(wf.shape[0], c).T
+        out[name] = np.ascontiguousarray(w.reshape(cin, kh, kw, -1).transpose(0, 3, 1, 2)).astype(np.float32)
+    return out
+
+
+def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True):
+    lw = Lowering(sym, input_shapes, multi_stream=multi_stream, fold_linear=fold_linear).run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

@@ -51,6 +51,7 @@ def _declare(lib):
         "accel_model_set_param": [vp, c.c_char_p, vp, i, c.POINTER(c.c_int64)],
         "accel_model_has_param": [vp, c.c_char_p],
         "accel_model_add_plan": [vp, c.c_char_p, c.c_char_p, c.POINTER(vp)],
+        "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],
         "accel_plan_num_ops": [vp],
@@ -224,7 +225,10 @@ class Plan(object):
         fl, by = ctypes.c_double(), ctypes.c_double()
         for i in range(n):
             check(lib().accel_plan_op_info(self.handle, i, kind, name, ctypes.byref(fl), ctypes.byref(by)))
-            out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value})
+            t, k, nw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib().accel_plan_op_launch(self.handle, i, ctypes.byref(t), ctypes.byref(k), ctypes.byref(nw)))
+            out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value,
+                        "tile": t.value, "ksplit": k.value, "narrow": nw.value})
         return out
 
     def profile(self, iters=3):

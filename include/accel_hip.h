@@ -73,6 +73,9 @@ int accel_plan_run(accel_plan* p);        /* enqueue one forward (Module.forward
 int accel_plan_num_ops(accel_plan* p);
 /* kind: up to 31 chars + NUL; flops/bytes: algorithmic work of op i (0 if n/a) */
 int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double* flops, double* bytes);
+/* launch decisions of op i after finalize (autotuned or heuristic): conv tile id (conv_igemm.hip, -1 for
+ * non-conv ops), split-K factor, 1 if the narrow-N kernel runs it.  Diagnostic only. */
+int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narrow);
 /* runs the plan `iters` times eagerly with a HIP event pair around every op on
  * the context stream; ms[i] = mean duration of op i */
 int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);

@@ -23,7 +23,7 @@ for nm, pred in (('key', runner.key_predictor), ('cur', runner.cur_predictor)):
         gbs = o['bytes'] / (t * 1e-3) / 1e9 if o['bytes'] else 0
         extra = ''
         if kind == 'conv':
-            extra = 'cin=%s cout=%s k=%s s=%s %s out=%s' % (args.get('cin'), args.get('cout'), args.get('k'), args.get('s'), args.get('mode'), args['out'].ref().split(':', 2)[2])
+            extra = 'cin=%s cout=%s k=%s s=%s %s out=%s tile=%s ksplit=%d' % (args.get('cin'), args.get('cout'), args.get('k'), args.get('s'), args.get('mode'), args['out'].ref().split(':', 2)[2], 'narrow' if o['narrow'] else o['tile'], o['ksplit'])
         rows.append((t, '%-10s %-28s %8.1f us %6.1f TF %7.0f GB/s  %s' % (kind, o['name'][:28], t * 1e3, tf, gbs, extra)))
     for t, r in rows:
         print(r)

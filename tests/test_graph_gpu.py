@@ -30,6 +30,27 @@ def _check(outs, ref, tag):
         assert float((lab != rlab[0]).mean()) < 1e-3
 
 
+@pytest.mark.parametrize("version", ["18", "34"])
+def test_clip_parity_without_linear_fold(demo_cfg, version, monkeypatch):
+    """ACCEL_FOLD_LINEAR=0 runs `feat_upsampling` and `fc6` as the reference's two separate layers; the default
+    (composed deconvolution) is what every other test in this file exercises.  Both must match the oracle."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    monkeypatch.setenv("ACCEL_FOLD_LINEAR", "0")
+    H, W, interval = 128, 256, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params(version, H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        runner_outs = demo.run_clip(version, demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, version, _oracle_frames(frames, demo_cfg), interval)
+    _check(runner_outs, ref, "accel-%s unfolded" % version)
+
+
 @pytest.mark.parametrize("version", ["18", "34", "50", "101"])
 def test_clip_parity_128x256(demo_cfg, version):
     from accel_amd import demo

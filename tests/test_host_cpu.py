@@ -108,20 +108,46 @@ def test_flownet_shape_trace_1024x2048(demo_cfg):
 
 
 # ---- lowering invariants -------------------------------------------------------------------
-def _plan(version, key, H=128, W=256):
+def _plan(version, key, H=128, W=256, **kw):
     from accel_amd import lower
     from accel_amd.config.config import config
     inst = _sym(version)
     sym = inst.get_key_test_symbol(config) if key else inst.get_cur_test_symbol(config)
-    return lower.lower(sym, _shapes(H, W, key))
+    return lower.lower(sym, _shapes(H, W, key), **kw)
 
 
 def test_algorithmic_flops_match_the_survey(demo_cfg):
-    """BASELINE.md section 4 (GFLOP per frame at 1024x2048), within 0.5 %"""
+    """BASELINE.md section 4 (GFLOP per frame at 1024x2048), within 0.5 %: the reference's layer list, i.e. the
+    plan lowered WITHOUT the feat_upsampling*fc6 fold.  The fold removes exactly the 2048-channel intermediate:
+    2*64*128*(4*512*2048 + 2048*1024 - 4*512*1024) flops (4 of the 16 taps reach each output pixel) on Accel-18/34, nothing elsewhere."""
     exp = {("18", True): 855.3, ("18", False): 381.2, ("34", False): 537.2, ("50", False): 679.3, ("101", False): 1076.8}
+    saved = 2.0 * 64 * 128 * (4 * 512 * 2048 + 2048 * 1024 - 4 * 512 * 1024) / 1e9
     for (v, key), gf in exp.items():
-        _, lw = _plan(v, key, 1024, 2048)
+        _, lw = _plan(v, key, 1024, 2048, fold_linear=False)
         assert abs(lw.total_flops / 1e9 - gf) / gf < 5e-3, (v, key, lw.total_flops / 1e9, gf)
+        assert not lw.derived
+        _, lwf = _plan(v, key, 1024, 2048)
+        cut = (lw.total_flops - lwf.total_flops) / 1e9
+        if v in ("18", "34") and not key:
+            assert abs(cut - saved) < 1e-6 * saved and len(lwf.derived) == 1
+        else:
+            assert cut == 0 and not lwf.derived
+
+
+def test_linear_fold_weight_is_the_composition():
+    """lower.fold_params: deconv4x4/2(x, Wd) -> conv1x1(., Wf) + b  ==  deconv4x4/2(x, Wd*Wf) + b  (oracle ops)."""
+    from accel_amd import lower
+    from oracle import ops
+    rng = np.random.RandomState(7)
+    x = rng.randn(1, 12, 5, 6).astype(np.float32)
+    wd = (rng.randn(12, 24, 4, 4) * 0.2).astype(np.float32)
+    wf = (rng.randn(8, 24, 1, 1) * 0.2).astype(np.float32)
+    b = rng.randn(8).astype(np.float32)
+    two = ops.conv2d(ops.deconv2d(x, wd, None, stride=2, pad=1), wf, b)
+    w = lower.fold_params({"a*b": ("deconv4x4s2*conv1x1", "a", "b")}, {"a": wd, "b": wf})["a*b"]
+    assert w.shape == (12, 8, 4, 4) and w.dtype == np.float32
+    one = ops.deconv2d(x, w, b, stride=2, pad=1)
+    np.testing.assert_allclose(one, two, rtol=0, atol=2e-5 * float(np.abs(two).max()))
 
 
 @pytest.mark.parametrize("version,key", [("18", True), ("18", False), ("34", False), ("50", False), ("101", False)])
