@@ -366,7 +366,12 @@ class Lowering(object):
         if out2 is not None:
             args.update({"out2": out2, "bn2": bn2.name, "eps2": bn2.attrs["eps"], "fixg2": int(bn2.attrs["fix_gamma"])})
             writes.append(out2)
-        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops)
+        # algorithmic HBM bytes of the launch: every operand once (input, weights, residual, outputs)
+        kk = a["kernel"][0] * a["kernel"][1]
+        in_elems = ho * wo * kk * _r4(cin) if op == "DeformableConvolution" else hi * wi * cin
+        w_elems = cout * cin * (16 if mode == "deconv2x" else kk)
+        nbytes = 4.0 * (in_elems + w_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
+        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes)
         self.absorbed.add(id(A))
         for n in chain:
             self.absorbed.add(id(n))

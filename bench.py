@@ -225,18 +225,29 @@ def _run(a):
         # dominant kernel = conv_igemm_f32 (implicit-GEMM conv on the fp32 matrix cores): HIP-event pair around
         # every launch on the compute stream, all conv launches of one clip (1 key + 4 non-key plans)
         kms, cms = key_plan.profile(2), cur_plan.profile(2)
-        fl = ms = n = 0.0
+        fl = ms = n = by = 0.0
         for plan, t, wgt in ((key_plan, kms, 1), (cur_plan, cms, a.interval - 1)):
             for op, d in zip(plan.ops(), t):
                 if op["kind"] == "conv":
                     fl += wgt * op["flops"]
+                    by += wgt * op["bytes"]
                     ms += wgt * float(d)
                     n += wgt
         clip_ms = float(kms.sum()) + (a.interval - 1) * float(cms.sum())
         ach = fl / (ms * 1e-3) / 1e12
         peak = MFMA_F32_PEAK_TFLOPS if a.dtype == "f32" else 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+        # HBM bytes per launch come from the committed PMC passes of this same command (counters cannot be read
+        # from inside the process): only reported for the workload they were collected on
+        traffic, traffic_note = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tj) and a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32" and len(lanes) == 1:
+            with open(tj) as f:
+                tr = json.load(f)
+            traffic = round(tr["read_bytes_per_launch"] + tr["write_bytes_per_launch"])
+            traffic_note = "bytes per launch, profiles/r01_pmc_traffic.json: " + tr["method"]
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                           "algorithmic_bytes_per_launch": round(by / n),
                            "kernel": "conv_igemm_f32_kernel (all tile variants)", "launches_per_clip": int(n),
                            "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                            "conv_ms_per_clip": round(ms, 3), "all_kernels_ms_per_clip": round(clip_ms, 3)}

@@ -8,6 +8,8 @@ LDS stores only) used for the breakdown quoted in DESIGN.md."""
 import sys, numpy as np
 sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..', '..'))
 from accel_amd import runtime
+if __import__('os').environ.get('ACCEL_LIB_PATH'):   # A/B two builds of the library on the same box
+    runtime.LIB_PATH = __import__('os').environ['ACCEL_LIB_PATH']
 SHAPES = [  # name, cin, cout, H, W (input), k, s, p, d, res, mode
     ("res4_2b 3x3 256-256 @64x128", 256, 256, 64, 128, 3, 1, 1, 1, 0, "conv"),
     ("res4_2a 1x1 1024-256", 1024, 256, 64, 128, 1, 1, 0, 1, 0, "conv"),
@@ -22,6 +24,15 @@ SHAPES = [  # name, cin, cout, H, W (input), k, s, p, d, res, mode
     ("feat_up deconv 512-2048 @32x64", 512, 2048, 32, 64, 4, 2, 1, 1, 0, "deconv2x"),
     ("r18 3x3 128-128 @128x256", 128, 128, 128, 256, 3, 1, 1, 1, 0, "conv"),
 ]
+if __import__('os').environ.get("STEADY"):   # long-K shapes: steady-state main loop with 2 / 4 / 8 blocks of 64x64 per CU
+    SHAPES = [
+        ("K=8192 N=256 M=8192 (2 blk/CU @64x64)", 8192, 256, 64, 128, 1, 1, 0, 1, 0, "conv"),
+        ("K=8192 N=256 M=16384 (4 blk/CU)", 8192, 256, 128, 128, 1, 1, 0, 1, 0, "conv"),
+        ("K=8192 N=512 M=16384 (8 blk/CU)", 8192, 512, 128, 128, 1, 1, 0, 1, 0, "conv"),
+        ("K=2304 N=256 M=8192  1x1", 2304, 256, 64, 128, 1, 1, 0, 1, 0, "conv"),
+        ("K=2304 N=256 M=8192  3x3", 256, 256, 64, 128, 3, 1, 1, 1, 0, "conv"),
+        ("K=2304 N=256 M=32768 3x3", 256, 256, 128, 256, 3, 1, 1, 1, 0, "conv"),
+    ]
 ctx = runtime.Context(0)
 tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [-1]
 for (name, cin, cout, H, W, k, s, p, d, res, mode) in SHAPES:

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Condenses rocprofv3 output directories into the tables kept under profiles/.
 
-  python scripts/summarize_rocprof.py <stats_dir> <pmc_sq_dir> <pmc_fetch_dir> <pmc_write_dir> > profiles/rNN_summary.md
+  python scripts/summarize_rocprof.py <stats_dir> <pmc_sq_dir> <pmc_fetch_dir> <pmc_write_dir> [traffic.json] > profiles/rNN_summary.md
+
+With a fifth argument the HBM traffic per launch of the conv_igemm_f32 family (all tile variants, launch-weighted) is
+also written as JSON; bench.py reports it as `roofline.traffic` for the same workload.
 
 PMC passes are separate runs (SQ counters / FETCH_SIZE / WRITE_SIZE cannot share
 a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Corrections applied as that
@@ -13,6 +16,7 @@ cycles), kernel cycles from GRBM_GUI_ACTIVE (summed over the 8 XCDs -> /8)."""
 import collections
 import csv
 import glob
+import json
 import sys
 
 
@@ -56,6 +60,20 @@ def main():
         ww = wr.get(k, {}).get("WRITE_SIZE", 0) * 1024 / max(nw.get(k, 1), 1) / 1e6
         print("| %s | %.1f %% | %.0f | %.0f | %.2f | %.1f | %.1f |" % (k, 100 * util, cyc / n, c.get("SQ_LDS_BANK_CONFLICT", 0) / n,
                                                                    wait, rd, ww))
+
+
+    if len(sys.argv) > 5:
+        fam = "conv_igemm_f32_kernel"
+        rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if fam in k) * 2 * 1024
+        nr = sum(n for k, n in nf.items() if fam in k)
+        ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if fam in k) * 1024
+        nwr = sum(n for k, n in nw.items() if fam in k)
+        json.dump({"kernel": fam + " (all tile variants)", "read_bytes_per_launch": rd / max(nr, 1),
+                   "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 8 "
+                             "--warmup 2 --no-cpu-baseline`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "
+                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"},
+                  open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":
