@@ -116,6 +116,9 @@ class Predictor(object):
                 model.set_param(name, w)
                 done[name] = id(self._arg_params)
             model._derived_from = done
+        for name, d in lw.derived_bufs.items():      # rebuild plans of the derived persistent buffers (featG = fc6_weight * feat)
+            if not self._is_key and ("init:" + name) not in model.plans:
+                model.add_plan("init:" + name, _lower.init_plan_text(name, d)).finalize()
         role = "key" if self._is_key else "cur"      # the roles accel_key_forward / accel_cur_forward look up
         if role in model.plans:
             role = "%s_%x" % (role, id(self) & 0xFFFFFF)

@@ -7,6 +7,7 @@
 // Parameters are referenced by their MXNet names and repacked here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -75,6 +76,14 @@ struct accel_model {
     std::vector<accel_plan*> plans;
     std::map<std::string, accel_plan*> roles;
     int feat_c = 0, feat_h = 0, feat_w = 0;     // shape of the propagated feature (`meta` line of the plans)
+    // derived persistent buffers (`pbuf name=featG from=feat`): a linear image of another buffer that the plans keep
+    // in step with it.  Writing the source from outside a plan that also writes the derived buffer makes it stale; a
+    // plan that reads a stale derived buffer first runs the model's `init:<name>` plan (see accel_plan_run).
+    std::map<std::string, std::string> derived_from;
+    std::map<std::string, bool> derived_valid;
+    void source_written(const std::string& src) {
+        for (auto& kv : derived_from) if (kv.second == src) derived_valid[kv.first] = false;
+    }
 };
 
 struct BufRef {
@@ -131,6 +140,7 @@ struct accel_plan {
     float* ws1 = nullptr;
     bool two_streams = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<std::string> pbuf_reads, pbuf_writes;   // persistent buffers the ops read / write (derived-buffer tracking)
 };
 
 // ---------------------------------------------------------------------------
@@ -260,6 +270,10 @@ static int parse_plan(accel_plan* p, const char* text)
             } else if (b.bytes < bytes) {
                 return fail(ACCEL_ERR_PLAN, "pbuf %s already exists with %zu bytes < %zu", name.c_str(), b.bytes, bytes);
             }
+            if (kv_has(kv, "from")) {
+                p->m->derived_from[name] = kv_str(kv, "from");
+                if (!p->m->derived_valid.count(name)) p->m->derived_valid[name] = false;
+            }
             continue;
         }
         Op op;
@@ -286,6 +300,15 @@ static int parse_plan(accel_plan* p, const char* text)
         else if (kind == "export_nchw") op.kind = OP_EXPORT_NCHW;
         else if (kind == "import_nchw") op.kind = OP_IMPORT_NCHW;
         else return fail(ACCEL_ERR_PLAN, "line %d: unknown op '%s'", lineno, kind.c_str());
+        for (const auto& e : kv) {
+            const size_t c0 = e.second.find(':');
+            if (c0 == std::string::npos || c0 == 0) continue;
+            const std::string space = e.second.substr(0, c0);
+            if (space == "A" || !p->m->pbufs.count(space)) continue;
+            const bool is_out = e.first == "out" || e.first == "out2" || e.first == "dst" || e.first == "logits" || e.first == "labels";
+            auto& v = is_out ? p->pbuf_writes : p->pbuf_reads;
+            if (std::find(v.begin(), v.end(), space) == v.end()) v.push_back(space);
+        }
         p->ops.push_back(op);
     }
     return 0;
@@ -447,9 +470,16 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.shift = static_cast<const float*>(db);
     if (op.c.set) {
         std::vector<float> s2(rows, 0.f), b2(rows, 0.f), s, b;
-        if (!kv_has(kv, "bn2")) return fail(ACCEL_ERR_PLAN, "conv %s: out2 needs bn2", op.name.c_str());
-        if ((rc = bn_fold(m, kv_str(kv, "bn2"), (float)kv_f(kv, "eps2", 2e-5), (int)kv_int(kv, "fixg2", 0), cout, s, b))) return rc;
-        for (int i = 0; i < cout; ++i) { s2[i] = s[i]; b2[i] = b[i]; }
+        if (kv_has(kv, "bias2")) {          // out2 = relu(v + bias2): the biased, activated copy beside a raw linear output
+            const HostParam* bias = get_param(m, kv_str(kv, "bias2"));
+            if (!bias) return fail(ACCEL_ERR_PARAM, "%s not initialized", kv_str(kv, "bias2").c_str());
+            if ((int)bias->numel() != cout) return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s", kv_str(kv, "bias2").c_str());
+            for (int i = 0; i < cout; ++i) { s2[i] = 1.f; b2[i] = bias->data[i]; }
+        } else {
+            if (!kv_has(kv, "bn2")) return fail(ACCEL_ERR_PLAN, "conv %s: out2 needs bn2 or bias2", op.name.c_str());
+            if ((rc = bn_fold(m, kv_str(kv, "bn2"), (float)kv_f(kv, "eps2", 2e-5), (int)kv_int(kv, "fixg2", 0), cout, s, b))) return rc;
+            for (int i = 0; i < cout; ++i) { s2[i] = s[i]; b2[i] = b[i]; }
+        }
         void *d2 = nullptr, *e2 = nullptr;
         if ((rc = dev_upload(p, s2.data(), rows * sizeof(float), &d2)) ||
             (rc = dev_upload(p, b2.data(), rows * sizeof(float), &e2))) return rc;
@@ -567,6 +597,15 @@ static int finalize_op(accel_plan* p, Op& op)
         if ((rc = parse_buf(kv, "feat", op.a)) || (rc = parse_buf(kv, "flow", op.b)) || (rc = parse_buf(kv, "out", op.c))) return rc;
         if ((rc = resolve(p, op.a, "feat")) || (rc = resolve(p, op.b, "flow")) || (rc = resolve(p, op.c, "out"))) return rc;
         if (op.a.C % 4) return fail(ACCEL_ERR_PLAN, "warp: C must be a multiple of 4");
+        if (kv_has(kv, "out2")) {           // second output relu(warped + bias[c])
+            if ((rc = parse_buf(kv, "out2", op.d)) || (rc = resolve(p, op.d, "out2"))) return rc;
+            const HostParam* bias = get_param(p->m, kv_str(kv, "bias"));
+            if (!bias) return fail(ACCEL_ERR_PARAM, "%s not initialized", kv_str(kv, "bias").c_str());
+            if ((int)bias->numel() != op.a.C) return fail(ACCEL_ERR_PARAM, "shape inconsistent for %s", kv_str(kv, "bias").c_str());
+            void* db = nullptr;
+            if ((rc = dev_upload(p, bias->data.data(), (size_t)op.a.C * sizeof(float), &db))) return rc;
+            op.p0 = static_cast<const float*>(db);
+        }
         return 0;
     }
     case OP_DCN_COLS: {
@@ -652,7 +691,8 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, st); break;
     case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, st); break;
     case OP_POOL: e = launch_pool(op.pool, st); break;
-    case OP_WARP: e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W, st); break;
+    case OP_WARP: e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W,
+                                       op.d.set ? op.d.ptr : nullptr, op.d.Cs, op.p0, st); break;
     case OP_DCN_COLS: e = launch_dcn_cols(op.dcn, st); break;
     case OP_SCORE_TAIL:
         if (op.tail_z) {
@@ -982,11 +1022,27 @@ extern "C" int accel_plan_finalize(accel_plan* p)
 extern "C" int accel_plan_run(accel_plan* p)
 {
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run: plan not finalized");
-    if (p->gexec) {
-        HIP_TRY(hipGraphLaunch(p->gexec, p->m->ctx->stream));
-        return 0;
+    accel_model* m = p->m;
+    // stale derived inputs are rebuilt from their source by the model's `init:<name>` plan (same stream: ordered)
+    for (const auto& r : p->pbuf_reads) {
+        auto d = m->derived_valid.find(r);
+        if (d == m->derived_valid.end() || d->second) continue;
+        auto ip = m->roles.find("init:" + r);
+        if (ip == m->roles.end() || ip->second == p || !ip->second->finalized)
+            return fail(ACCEL_ERR_PLAN, "persistent buffer '%s' is stale and the model has no finalized 'init:%s' plan", r.c_str(), r.c_str());
+        int rc = accel_plan_run(ip->second);
+        if (rc) return rc;
     }
-    return run_eager(p);
+    int rc = 0;
+    if (p->gexec) {
+        if (hipGraphLaunch(p->gexec, m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipGraphLaunch failed");
+    } else {
+        rc = run_eager(p);
+    }
+    for (const auto& w : p->pbuf_writes) m->source_written(w);
+    for (const auto& w : p->pbuf_writes)
+        if (m->derived_valid.count(w)) m->derived_valid[w] = true;
+    return rc;
 }
 
 extern "C" int accel_plan_num_ops(accel_plan* p) { return p ? (int)p->ops.size() : 0; }
@@ -1048,6 +1104,7 @@ extern "C" int accel_model_write(accel_model* m, const char* buf, const void* sr
     if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_write: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
     HIP_TRY(hipMemcpyAsync(it->second.ptr, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
     if (!src_on_device) HIP_TRY(hipStreamSynchronize(m->ctx->stream));   // pageable source may be reused by the caller
+    m->source_written(buf);
     return 0;
 }
 
@@ -1069,6 +1126,7 @@ extern "C" int accel_model_buffer(accel_model* m, const char* buf, void** dev_pt
     if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_buffer: unknown buffer '%s'", buf);
     if (dev_ptr) *dev_ptr = it->second.ptr;
     if (bytes) *bytes = it->second.bytes;
+    if (dev_ptr) m->source_written(buf);   // the caller may write through the raw pointer: derived buffers become stale
     return 0;
 }
 

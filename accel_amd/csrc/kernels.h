@@ -67,8 +67,10 @@ struct PoolParams {
 hipError_t launch_pool(const PoolParams& p, hipStream_t st);
 
 // GridGenerator(warp)+BilinearSampler fused; flow is NHWC (ch0 = dx, ch1 = dy)
+// optional second output out2 = relu(warped + bias[c]) (bias: C floats)
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs,
-                            float* out, int oCs, int C, int H, int W, hipStream_t st);
+                            float* out, int oCs, int C, int H, int W,
+                            float* out2, int o2Cs, const float* bias, hipStream_t st);
 
 struct DcnColsParams {
     const float* x; const float* off; float* col;

@@ -125,7 +125,8 @@ hipError_t launch_pool(const PoolParams& p, hipStream_t st)
 // ---------------------------------------------------------------------------
 __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
                                  const float* __restrict__ flow, int flCs,
-                                 float* __restrict__ out, int oCs, int C4, int H, int W)
+                                 float* __restrict__ out, int oCs, int C4, int H, int W,
+                                 float* __restrict__ out2, int o2Cs, const float* __restrict__ bias)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)H * W * C4) return;
@@ -158,15 +159,21 @@ __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
     o.w = tl.w * wy * wx + tr.w * wy * (1.0f - wx) + bl.w * (1.0f - wy) * wx + br.w * (1.0f - wy) * (1.0f - wx);
     (void)w00; (void)w01; (void)w10; (void)w11;
     *reinterpret_cast<float4*>(out + (size_t)pix * oCs + c4 * 4) = o;
+    if (out2) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        float4 r;
+        r.x = fmaxf(o.x + b.x, 0.f); r.y = fmaxf(o.y + b.y, 0.f); r.z = fmaxf(o.z + b.z, 0.f); r.w = fmaxf(o.w + b.w, 0.f);
+        *reinterpret_cast<float4*>(out2 + (size_t)pix * o2Cs + c4 * 4) = r;
+    }
 }
 
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs, float* out, int oCs,
-                            int C, int H, int W, hipStream_t st)
+                            int C, int H, int W, float* out2, int o2Cs, const float* bias, hipStream_t st)
 {
     const int C4 = C / 4;
     const long total = (long)H * W * C4;
     hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, feat, fCs, flow, flCs,
-                       out, oCs, C4, H, W);
+                       out, oCs, C4, H, W, out2, o2Cs, bias);
     return hipGetLastError();
 }
 

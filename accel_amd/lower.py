@@ -76,6 +76,7 @@ class Lowering(object):
         self.sym = sym
         self.fold_linear = bool(fold_linear)
         self.derived = {}      # derived parameter name -> ("deconv4x4s2*conv1x1", deconv weight, conv weight)
+        self.derived_bufs = {} # derived persistent buffer -> {"from", "w", "cin", "cout", "H", "W"} (see lower_warp)
         self.shapes = infer_shapes(sym, input_shapes)
         self.nodes = sym.topo()
         self.heads = sym._heads()
@@ -135,6 +136,28 @@ class Lowering(object):
         b = VBuf(-1, Cs, H, W, space=name)
         self.pbufs[name] = max(self.pbufs.get(name, 0), H * W * Cs * 4)
         return View(b, C)
+
+    def _head_on_feature(self, conv, feature):
+        """`conv` = 1x1/1 Convolution with bias on the propagated feature whose only consumer is a ReLU
+        (the DeepLab head's fc6): returns that ReLU node, else None."""
+        a = conv.attrs
+        if not self.fold_linear or conv.op != "Convolution" or conv.inputs[0] is not feature:
+            return None
+        if a["kernel"] != (1, 1) or a["stride"] != (1, 1) or a["pad"] != (0, 0) or a["num_group"] != 1 or a["no_bias"]:
+            return None
+        if a["num_filter"] % 4 or id(conv) in self.head_ids:
+            return None
+        cons = self.consumers(conv)
+        if len(cons) != 1 or cons[0].op != "Activation" or cons[0].attrs["act_type"] != "relu":
+            return None
+        return cons[0]
+
+    def _feat_image(self, conv, C, H, W):
+        """The derived persistent buffer featG = W_conv * feat (no bias), kept in step with `feat` by the plans."""
+        _, cin, _, _ = self.shape(conv.inputs[0])
+        v = self.pbuf_view("featG", C, H, W)
+        self.derived_bufs["featG"] = {"from": "feat", "w": conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W}
+        return v
 
     def dest_for(self, node):
         """Where the value of `node` must be written."""
@@ -314,10 +337,18 @@ class Lowering(object):
         if need_crop and not cropped:
             raise NotImplementedError("Deconvolution %s pad 0 without Crop" % A.name)
 
+        # key frame: the head's 1x1 conv on the propagated feature also leaves its raw linear image W*feat in the
+        # derived buffer `featG`; non-key frames then warp that image instead of re-running the conv (lower_warp)
+        feat_image = None
+        if op == "Convolution" and x.op != "null" and id(x) in self.head_ids and x.name == "res5c_relu" \
+                and self._head_on_feature(A, x) is not None and chain == [self._head_on_feature(A, x)] \
+                and bn is None and mul is None and res is None:
+            _, co_, ho_, wo_ = self.shape(A)
+            feat_image = self._feat_image(A, co_, ho_, wo_)
         out = self.dest_for(cur)
         # dual output: relu(bn(.)) of the value for the next pre-activation unit
         out2, bn2, chain2 = None, None, []
-        if True:
+        if feat_image is None:
             for n in self.consumers(cur):
                 if n.op == "BatchNorm" and id(n) not in self.absorbed:
                     c2 = self.consumers(n)
@@ -331,6 +362,10 @@ class Lowering(object):
         _, cin, hi, wi = self.shape(x)
         _, cout, ho, wo = self.shape(cur)
         args = {"name": opname, "out": out, "w": wname, "act": act, "slope": slope, "cin": cin, "cout": cout, "mode": mode}
+        bias2 = None
+        if feat_image is not None:
+            out2, out, act, bias2, bias = out, feat_image, 0, bias, None
+            args.update({"out": out, "act": 0})
         reads = [res]
         if op == "DeformableConvolution":
             off = A.inputs[1]
@@ -363,7 +398,10 @@ class Lowering(object):
         if res is not None:
             args["res"] = res
         writes = [out]
-        if out2 is not None:
+        if bias2 is not None:
+            args.update({"out2": out2, "bias2": bias2})
+            writes.append(out2)
+        elif out2 is not None:
             args.update({"out2": out2, "bn2": bn2.name, "eps2": bn2.attrs["eps"], "fixg2": int(bn2.attrs["fix_gamma"])})
             writes.append(out2)
         # algorithmic HBM bytes of the launch: every operand once (input, weights, residual, outputs)
@@ -373,6 +411,8 @@ class Lowering(object):
         nbytes = 4.0 * (in_elems + w_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
         self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes)
         self.absorbed.add(id(A))
+        if feat_image is not None:
+            out, out2 = out2, None     # the graph value of the chain is the biased, activated copy
         for n in chain:
             self.absorbed.add(id(n))
             self.val[id(n)] = out
@@ -469,6 +509,29 @@ class Lowering(object):
             dst = self.pbuf_view("feat", C, H, W)
             self.emit("copy", {"src": out, "dst": dst}, [out], [dst], nbytes=8.0 * C * H * W)
             self.outputs[B.name + "_output"] = dst
+        # Warp and a 1x1 convolution commute (both linear, the bilinear weights do not depend on the channel):
+        #   relu(W * warp(F) + b) = relu(warp(W * F) + b),
+        # out-of-image taps contribute zero on both sides, so the bias stays outside the warp.  The head's fc6 on the
+        # warped feature (34.4 GFLOP at 1024x2048) becomes a warp of the 1024-channel image featG = W*F that the key
+        # plan (or, after a host upload of `feat`, the init:featG plan) left in HBM; the warped image is also the next
+        # frame's featG (iterative warping: F_t = warp(F_t-1)  =>  W*F_t = warp(W*F_t-1)).
+        heads = [c for c in self.consumers(B) if self._head_on_feature(c, B) is not None]
+        if feat.op == "null" and feat.name == "feat_key" and id(B) in self.head_ids \
+                and len(self.consumers(B)) == 1 and len(heads) == 1:
+            conv = heads[0]
+            relu = self._head_on_feature(conv, B)
+            _, Cg, _, _ = self.shape(conv)
+            g_in = self._feat_image(conv, Cg, H, W)
+            g_out = View(self.new_buf(Cg, H, W), Cg)
+            act_out = self.dest_for(relu)
+            self.emit("warp", {"name": B.name + "*" + conv.name, "feat": g_in, "flow": flow, "out": g_out, "out2": act_out,
+                               "bias": conv.inputs[2].name}, [g_in, flow], [g_out, act_out],
+                      nbytes=3.0 * 4 * Cg * H * W + 8.0 * H * W)
+            g_dst = self.pbuf_view("featG", Cg, H, W)
+            self.emit("copy", {"src": g_out, "dst": g_dst}, [g_out], [g_dst], nbytes=8.0 * Cg * H * W)
+            self.absorbed.update((id(conv), id(relu)))
+            self.val[id(conv)] = act_out
+            self.val[id(relu)] = act_out
 
     # ---- score tail --------------------------------------------------------------------------------
     @staticmethod
@@ -605,7 +668,8 @@ class Lowering(object):
         lines.append("meta feat_c=2048 feat_h=%d feat_w=%d" % (self.H // 16, self.W // 16))
         lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
         for name, nbytes in sorted(self.pbufs.items()):
-            lines.append("pbuf name=%s bytes=%d" % (name, nbytes))
+            src = self.derived_bufs.get(name, {}).get("from")
+            lines.append("pbuf name=%s bytes=%d%s" % (name, nbytes, " from=%s" % src if src else ""))
         for kind, args in self.ops:
             toks = [kind]
             for k, v in args.items():
@@ -638,6 +702,21 @@ def fold_params(derived, params):
         w = wd.transpose(0, 2, 3, 1).reshape(cin * kh * kw, c) @ wf.reshape(wf.shape[0], c).T
         out[name] = np.ascontiguousarray(w.reshape(cin, kh, kw, -1).transpose(0, 3, 1, 2)).astype(np.float32)
     return out
+
+
+def init_plan_text(name, d):
+    """Plan of role `init:<name>` that rebuilds a derived persistent buffer from its source (run by
+    accel_plan_run when a plan reads the buffer while it is stale, e.g. after a host upload of `feat`)."""
+    H, W, cin, cout = d["H"], d["W"], d["cin"], d["cout"]
+    return "\n".join([
+        "# accel_amd plan: rebuild %s = %s * %s" % (name, d["w"], d["from"]),
+        "option graph=0",
+        "arena bytes=%d" % ALIGN,
+        "pbuf name=%s bytes=%d" % (d["from"], H * W * _r4(cin) * 4),
+        "pbuf name=%s bytes=%d from=%s" % (name, H * W * _r4(cout) * 4, d["from"]),
+        "conv name=init_%s out=%s:0:%d:%d:%d:%d w=%s act=0 slope=0.1 cin=%d cout=%d mode=conv in=%s:0:%d:%d:%d:%d "
+        "k=1,1 s=1,1 p=0,0 d=1,1 flops=%g" % (name, name, cout, _r4(cout), H, W, d["w"], cin, cout,
+                                           d["from"], cin, _r4(cin), H, W, 2.0 * H * W * cin * cout)]) + "\n"
 
 
 def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True):

@@ -119,19 +119,25 @@ def _plan(version, key, H=128, W=256, **kw):
 def test_algorithmic_flops_match_the_survey(demo_cfg):
     """BASELINE.md section 4 (GFLOP per frame at 1024x2048), within 0.5 %: the reference's layer list, i.e. the
     plan lowered WITHOUT the feat_upsampling*fc6 fold.  The fold removes exactly the 2048-channel intermediate:
-    2*64*128*(4*512*2048 + 2048*1024 - 4*512*1024) flops (4 of the 16 taps reach each output pixel) on Accel-18/34, nothing elsewhere."""
+    2*64*128*(4*512*2048 + 2048*1024 - 4*512*1024) flops (4 of the 16 taps reach each output pixel) on Accel-18/34;
+    the warp/fc6 commutation removes the L head's fc6 (2*64*128*2048*1024) from every score-fusion non-key plan."""
     exp = {("18", True): 855.3, ("18", False): 381.2, ("34", False): 537.2, ("50", False): 679.3, ("101", False): 1076.8}
     saved = 2.0 * 64 * 128 * (4 * 512 * 2048 + 2048 * 1024 - 4 * 512 * 1024) / 1e9
+    head = 2.0 * 64 * 128 * 2048 * 1024 / 1e9      # fc6 on the warped feature -> warp of the key frame's W*feat image
     for (v, key), gf in exp.items():
         _, lw = _plan(v, key, 1024, 2048, fold_linear=False)
         assert abs(lw.total_flops / 1e9 - gf) / gf < 5e-3, (v, key, lw.total_flops / 1e9, gf)
-        assert not lw.derived
+        assert not lw.derived and not lw.derived_bufs
         _, lwf = _plan(v, key, 1024, 2048)
         cut = (lw.total_flops - lwf.total_flops) / 1e9
-        if v in ("18", "34") and not key:
-            assert abs(cut - saved) < 1e-6 * saved and len(lwf.derived) == 1
-        else:
-            assert cut == 0 and not lwf.derived
+        if key:
+            assert cut == 0 and not lwf.derived and list(lwf.derived_bufs) == ["featG"]
+        elif v in ("18", "34"):
+            assert abs(cut - saved - head) < 1e-6 * saved and len(lwf.derived) == 1 and list(lwf.derived_bufs) == ["featG"]
+        elif v == "50":
+            assert abs(cut - head) < 1e-6 * head and not lwf.derived and list(lwf.derived_bufs) == ["featG"]
+        else:      # Accel-101 fuses features: its fc6 runs on the `correction` output, not on the warped feature
+            assert cut == 0 and not lwf.derived and not lwf.derived_bufs
 
 
 def test_linear_fold_weight_is_the_composition():
@@ -186,7 +192,8 @@ def test_plan_is_well_formed(demo_cfg, version, key):
     kinds = [k for k, _ in lw.ops]
     assert kinds.count("score_tail") == 1
     if not key:
-        assert kinds.count("warp") == 1 and kinds.count("prep_flow") == 1 and kinds.count("copy") == 1
+        n = 1 if version == "101" else 2     # score-fusion models also warp the W*feat image (featG)
+        assert kinds.count("warp") == n and kinds.count("prep_flow") == 1 and kinds.count("copy") == n
     assert "Concat" not in text and all(k in ("prep_rgb", "prep_flow", "conv", "pool", "warp", "dcn_cols", "score_tail", "copy") for k in kinds)
 
 
