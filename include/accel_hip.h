@@ -69,7 +69,14 @@ int accel_model_has_param(accel_model* m, const char* name);
  * label; plans of one model share the model's persistent buffers by name. */
 int accel_model_add_plan(accel_model* m, const char* role, const char* plan_text, accel_plan** out);
 int accel_plan_finalize(accel_plan* p);   /* repack weights, allocate arena, capture hipGraph */
-int accel_plan_run(accel_plan* p);        /* enqueue one forward (Module.forward, module.py:1011) */
+/* enqueue one forward (Module.forward, module.py:1011).
+ * Derived persistent buffers: a plan line `pbuf name=featG bytes=.. from=feat` declares featG a function of
+ * `feat` that the plans keep in step with it (featG = fc6_weight * feat: non-key plans warp it instead of
+ * re-running fc6 on the warped feature).  A plan that writes both leaves featG valid; any other write of `feat`
+ * (accel_model_write, a raw pointer from accel_model_buffer, a plan that writes only `feat`) makes it stale, and
+ * the next plan that READS featG first runs the plan registered under the role "init:featG" -- or fails with
+ * ACCEL_ERR_PLAN if there is none.  Never silently reads a stale buffer. */
+int accel_plan_run(accel_plan* p);
 int accel_plan_num_ops(accel_plan* p);
 /* kind: up to 31 chars + NUL; flops/bytes: algorithmic work of op i (0 if n/a) */
 int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double* flops, double* bytes);
