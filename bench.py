@@ -220,7 +220,10 @@ def _run(a):
                                       "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step"
                                       % (a.version, a.version, H, W, a.interval, len(lanes), a.interval - 1),
                           "frames_per_step_per_gpu": a.interval * len(lanes), "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
-                          "gather": gather_note, "weights": "seeded random", "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
+                          "gather": gather_note, "weights": "seeded random",
+                          "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
+                                       "taken from the warped W_fc6*feat image of the key frame" if os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
+                                       else "reference layer list one to one (ACCEL_FOLD_LINEAR=0)"), "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
     if rank == 0 and not a.no_roofline:
         # dominant kernel = conv_igemm_f32 (implicit-GEMM conv on the fp32 matrix cores): HIP-event pair around
         # every launch on the compute stream, all conv launches of one clip (1 key + 4 non-key plans)
