@@ -33,6 +33,9 @@ if __import__('os').environ.get("STEADY"):   # long-K shapes: steady-state main 
         ("K=2304 N=256 M=8192  3x3", 256, 256, 64, 128, 3, 1, 1, 1, 0, "conv"),
         ("K=2304 N=256 M=32768 3x3", 256, 256, 128, 256, 3, 1, 1, 1, 0, "conv"),
     ]
+if __import__('os').environ.get("KSWEEP"):   # time vs K at fixed M, N: slope = steady-state rate, intercept = fixed cost per launch
+    SHAPES = [("K=%d N=256 M=8192" % k, k, 256, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 64, 128, 256, 512, 1024, 2304, 4608, 8192)]
+    SHAPES += [("K=%d N=1024 M=8192" % k, k, 1024, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 256, 1024, 4096)]
 ctx = runtime.Context(0)
 tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [-1]
 for (name, cin, cout, H, W, k, s, p, d, res, mode) in SHAPES:
