@@ -28,6 +28,20 @@
 #include <cstdlib>
 #include "kernels.h"
 
+// Diagnostic build only (-DACCEL_CONV_TIMELINE, scripts/microbench/timeline.py): per-block timestamps of the pipelined
+// kernel (entry / first tile in LDS / K loop done / stores retired) on the 100 MHz constant clock.
+#ifdef ACCEL_CONV_TIMELINE
+__device__ unsigned long long g_conv_timeline[8 * 16384];
+#define CONV_TL(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 16384) \
+        g_conv_timeline[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int accel_debug_conv_timeline(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define CONV_TL(slot) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -298,13 +312,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx][i][r], fb[idx][j][r], acc[i][j], 0, 0, 0);
         };
         const int nk = kt_end - kt_begin;
+        CONV_TL(0);
         load_tiles(kt_begin * BK);
         store_tiles(0);
         __syncthreads();
+        CONV_TL(1);
         if (nk > 1) load_tiles((kt_begin + 1) * BK);
         read_frags(0, 0, 0);
         int cur = 0;
         for (int k = 0; k < nk; ++k) {
+#ifdef ACCEL_CONV_TIMELINE
+            if (k == nk / 8) CONV_TL(4); else if (k == nk / 4) CONV_TL(5); else if (k == nk / 2) CONV_TL(6); else if (k == (3 * nk) / 4) CONV_TL(7);
+#endif
 #pragma unroll
             for (int t = 0; t < T - 1; ++t) {
                 read_frags(cur, t + 1, (t + 1) & 1);
@@ -335,7 +354,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
             }
             cur ^= 1;
         }
+        CONV_TL(2);
         conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+#ifdef ACCEL_CONV_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0);
+        CONV_TL(3);
+#endif
         return;
     }
 
