@@ -63,7 +63,9 @@ def build_batches(frames_bgr, cfg):
     for im in frames_bgr:
         target_size, max_size = cfg.SCALES[0][0], cfg.SCALES[0][1]
         im, _ = resize(im, target_size, max_size, stride=cfg.network.IMAGE_STRIDE)
-        im_tensor = transform(im, cfg.network.PIXEL_MEANS)
+        # one fp32 host image per frame, shared by this frame's `data` handle and the next frame's `data_key` handle:
+        # the Predictor recognises the shared buffer and copies it inside HBM instead of uploading it twice
+        im_tensor = np.ascontiguousarray(transform(im, cfg.network.PIXEL_MEANS), dtype=np.float32)
         if prev is None:
             prev = im_tensor
         data.append([mx.nd.array(im_tensor), mx.nd.array(prev),

@@ -264,9 +264,11 @@ class Model(object):
 
     def write(self, buf, arr):
         a = np.ascontiguousarray(arr)
+        self.__dict__.get("_resident", {}).pop(buf, None)     # Predictor's record of which host array is in `buf`
         check(lib().accel_model_write(self.handle, buf.encode(), _fp(a), a.nbytes, 0))
 
     def write_device(self, buf, dev_ptr, nbytes):
+        self.__dict__.get("_resident", {}).pop(buf, None)
         check(lib().accel_model_write(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
 
     def read(self, buf, shape, dtype=np.float32):
@@ -294,6 +296,7 @@ class Model(object):
         img = _f32(img)
         H, W = img.shape[-2:]
         f, lg, lb = self._outs(want, H, W)
+        self.__dict__.get("_resident", {}).clear()
         check(lib().accel_key_forward(self.handle, _fp(img), 0, None if f is None else _fp(f), None if lg is None else _fp(lg),
                                       None if lb is None else _fp(lb), 0))
         return {k: v for k, v in (("feat", f), ("logits", lg), ("labels", lb)) if v is not None}
@@ -302,6 +305,7 @@ class Model(object):
         a, b = _f32(img_cur), _f32(img_prev)
         H, W = a.shape[-2:]
         f, lg, lb = self._outs(want, H, W)
+        self.__dict__.get("_resident", {}).clear()
         check(lib().accel_cur_forward(self.handle, _fp(a), _fp(b), 0, None if f is None else _fp(f),
                                       None if lg is None else _fp(lg), None if lb is None else _fp(lb), 0))
         return {k: v for k, v in (("feat", f), ("logits", lg), ("labels", lb)) if v is not None}
