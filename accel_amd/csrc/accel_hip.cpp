@@ -640,6 +640,12 @@ static int finalize_op(accel_plan* p, Op& op)
         q.logits = op.c.ptr; q.labels = reinterpret_cast<unsigned char*>(op.d.ptr);
         const size_t wn = (size_t)q.ncls * 32 * 32;
         if ((rc = upload_param(p, kv_str(kv, "wl"), wn, &q.wl))) return rc;
+        if (!op.b.set) {      // single head: the wide kernel applies when one filter serves every class
+            const HostParam* hl = get_param(p->m, kv_str(kv, "wl"));
+            bool uni = hl && kv_int(kv, "lowres", 1) != 0;
+            for (int c = 1; c < q.ncls && uni; ++c) uni = !memcmp(hl->data.data(), hl->data.data() + (size_t)c * 1024, 4096);
+            q.uniform_w = uni ? 1 : 0;
+        }
         if (op.b.set) {
             q.right = op.b.ptr; q.rCs = op.b.Cs;
             if ((rc = upload_param(p, kv_str(kv, "wr"), wn, &q.wr)) ||
@@ -662,6 +668,7 @@ static int finalize_op(accel_plan* p, Op& op)
                 op.tail_lowres = q;
                 op.tail_lowres.left = op.tail_z; op.tail_lowres.lCs = zCs;
                 op.tail_lowres.right = nullptr; op.tail_lowres.wr = nullptr; op.tail_lowres.cw = nullptr;   // cb stays: bias after upsampling
+                op.tail_lowres.uniform_w = 1;
             }
         }
         return 0;

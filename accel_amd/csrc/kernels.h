@@ -90,6 +90,7 @@ struct ScoreTailParams {
     unsigned char* labels;           // H x W
     int ncls, Hs, Ws, H, W;
     int softmax;                     // apply softmax over classes to the written scores (deeplab test symbol)
+    int uniform_w;                   // wl is the same 32x32 filter for every class: 4-pixel-per-thread kernel
 };
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
 

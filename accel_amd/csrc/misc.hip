@@ -313,8 +313,83 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
     p.labels[o] = (unsigned char)best;
 }
 
+// Same tail for the common case "one score map, one upsampling filter shared by all classes" (the reference freezes
+// the 32x32/16 filters at the bilinear init; the two-head fusion has already run at score resolution): a thread owns
+// 4 consecutive pixels -- they share their 2x2 source cell since (X+8) % 16 is a multiple of 4 -- so the filter taps
+// are 4 float4 loads instead of 4*NCLS scalars and every class plane is written with 16-byte stores.
+// Per-pixel arithmetic (tap order, fma form) is the one of score_tail_kernel.
+template <int NCLS>
+__global__ __launch_bounds__(256) void score_tail_uniform_kernel(ScoreTailParams p)
+{
+    const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= p.W || Y >= p.H) return;
+    const int yy = Y + 8, xx = X + 8;
+    const int i0 = yy >> 4, ky0 = yy & 15, j0 = xx >> 4, kx0 = xx & 15;
+    float o[NCLS][4];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) o[c][0] = o[c][1] = o[c][2] = o[c][3] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int i = i0 - a, ky = ky0 + 16 * a;
+        if (i < 0 || i >= p.Hs) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 - b, kx = kx0 + 16 * b;
+            if (j < 0 || j >= p.Ws) continue;
+            const float* sp = p.left + ((size_t)i * p.Ws + j) * p.lCs;
+            const float4 w = *reinterpret_cast<const float4*>(p.wl + ky * 32 + kx);
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const float s = sp[c];
+                o[c][0] += w.x * s; o[c][1] += w.y * s; o[c][2] += w.z * s; o[c][3] += w.w * s;
+            }
+        }
+    }
+    if (p.cb) {
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            const float bb = p.cb[c];
+            o[c][0] += bb; o[c][1] += bb; o[c][2] += bb; o[c][3] += bb;
+        }
+    }
+    if (p.softmax) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float mx = o[0][q];
+#pragma unroll
+            for (int k = 1; k < NCLS; ++k) mx = fmaxf(mx, o[k][q]);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) { o[k][q] = expf(o[k][q] - mx); sum += o[k][q]; }
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) o[k][q] = o[k][q] / sum;
+        }
+    }
+    const size_t HW = (size_t)p.H * p.W, off = (size_t)Y * p.W + X;
+    int best[4] = {0, 0, 0, 0};
+    float bv[4] = {o[0][0], o[0][1], o[0][2], o[0][3]};
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) {
+        *reinterpret_cast<float4*>(p.logits + k * HW + off) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k > 0 && o[k][q] > bv[q]) { bv[q] = o[k][q]; best[q] = k; }
+    }
+    *reinterpret_cast<uchar4*>(p.labels + off) = make_uchar4((unsigned char)best[0], (unsigned char)best[1],
+                                                             (unsigned char)best[2], (unsigned char)best[3]);
+}
+
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st)
 {
+    if (p.uniform_w && !p.right && p.W % 4 == 0) {
+        dim3 g4(cdiv(p.W / 4, 64), cdiv(p.H, 4));
+        if (p.ncls == 19) hipLaunchKernelGGL(score_tail_uniform_kernel<19>, g4, dim3(256), 0, st, p);
+        else if (p.ncls == 2) hipLaunchKernelGGL(score_tail_uniform_kernel<2>, g4, dim3(256), 0, st, p);
+        else if (p.ncls == 21) hipLaunchKernelGGL(score_tail_uniform_kernel<21>, g4, dim3(256), 0, st, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     dim3 grid(cdiv(p.W, 64), cdiv(p.H, 4));
     if (p.ncls == 19) hipLaunchKernelGGL(score_tail_kernel<19>, grid, dim3(256), 0, st, p);
     else if (p.ncls == 2) hipLaunchKernelGGL(score_tail_kernel<2>, grid, dim3(256), 0, st, p);
