@@ -286,6 +286,90 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f32_kernel(ConvPara
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
+    if constexpr (MID == 3) {
+        // Deep-prefetch schedule.  Two register tiles are in flight: tile k+1 (loaded two K steps ago) is written to the
+        // other LDS buffer in the SECOND quarter of step k's MFMAs, so the ds_write latency and the barrier sit behind
+        // eight more MFMAs instead of one; the registers just freed receive tile k+3, giving every global load ~1.75
+        // K steps (> HBM latency) to land.  The barrier is an LDS-only one (`s_waitcnt lgkmcnt(0); s_barrier`):
+        // __syncthreads() would drain the global loads that are deliberately left in flight.  Scheduling fences
+        // between the four quarters keep the compiler from hoisting the store/barrier chain back up.
+        constexpr int T = BK / 8;
+        static_assert(T == 4, "the deep-prefetch schedule is written for BK = 32");
+        f32x4 fa[2][MI], fb[2][NI];
+        f32x4 ra1[AR], rb1[BR];
+        auto load_into = [&](f32x4 (&A)[AR], f32x4 (&B)[BR], int k0) {
+            const int4 tk = tk_next;
+            tk_next = ktab[(k0 + BK + (FAST ? 0 : scol)) / 4];
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                A[i] = buf_load4(xr, ok ? a_off[i] - (FAST ? 0u : scol * 4u) + (unsigned)tk.z : OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                B[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr_, b_off[i], k0 * 4, 0));
+        };
+        auto store_from = [&](const f32x4 (&A)[AR], const f32x4 (&B)[BR], int buf) {
+            float* a = As + buf * BM * LDK;
+            float* b = Bs + buf * BN * LDK;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(a + (srow + RP * i) * LDK + scol) = A[i];
+#pragma unroll
+            for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(b + (srow + RP * i) * LDK + scol) = B[i];
+        };
+        auto read_frags = [&](int buf, int t, int idx) {
+            const float* a = As + buf * BM * LDK + (wm * MI * 32 + frow) * LDK + fk + t * 8;
+            const float* b = Bs + buf * BN * LDK + (wn * NI * 32 + frow) * LDK + fk + t * 8;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[idx][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[idx][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDK);
+        };
+        auto mfma_step = [&](int idx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx][i][r], fb[idx][j][r], acc[i][j], 0, 0, 0);
+        };
+        auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        const int nk = kt_end - kt_begin;
+        load_into(ra, rb, kt_begin * BK);              // tile 0
+        load_into(ra1, rb1, (kt_begin + 1) * BK);      // tile 1 (past-the-end tiles read zeros / slack, never used)
+        store_from(ra, rb, 0);
+        lds_barrier();
+        load_into(ra, rb, (kt_begin + 2) * BK);        // tile 2
+        read_frags(0, 0, 0);
+        // one K step: LDS buffer `cur` holds tile k, (An, Bn) hold tile k+1 and are refilled with tile k+3
+        auto body = [&](int k, int cur, f32x4 (&An)[AR], f32x4 (&Bn)[BR]) {
+            read_frags(cur, 1, 1);
+            mfma_step(0);
+            __builtin_amdgcn_sched_barrier(0);
+            store_from(An, Bn, cur ^ 1);
+            read_frags(cur, 2, 0);
+            mfma_step(1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_into(An, Bn, (kt_begin + k + 3) * BK);
+            read_frags(cur, 3, 1);
+            mfma_step(0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_barrier();
+            read_frags(cur ^ 1, 0, 0);
+            mfma_step(1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int k = 0;
+        for (; k + 1 < nk; k += 2) {
+            body(k, 0, ra1, rb1);
+            body(k + 1, 1, ra, rb);
+        }
+        if (k < nk) body(k, 0, ra1, rb1);
+        conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+        return;
+    }
     if (MID == 2) {
         // Software-pipelined schedule.  Registers hold tile k+1 in flight for a whole K step; it is
         // written to the other LDS buffer behind the second-to-last fragment step, the (single) barrier
@@ -845,6 +929,7 @@ static void tile_dims(int tile, int& bm, int& bn)
 {
     static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 256, 128, 128, 64, 128, 64};
     static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
+    if (tile >= 31 && tile <= 35) { static const int g[5] = {3, 0, 2, 1, 4}; tile = g[tile - 31]; }   // deep-prefetch variants
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
     if (tile < 0 || tile > 19) tile = 3;
     bm = BMs[tile]; bn = BNs[tile];
@@ -918,6 +1003,11 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 13: return launch_cfg<64, 64, 2, 2, 64, 2>(p, st);     // BK 64
         case 14: return launch_cfg<256, 128, 4, 2, 32, 2>(p, st);   // 8 waves, wave tile 64x64 (110 KB LDS, 1 block/CU)
         case 15: return launch_cfg<128, 128, 2, 2, 16, 0>(p, st);   // BK 16: half the LDS, 4 blocks/CU
+        case 31: return launch_cfg<64, 64, 2, 2, 32, 3>(p, st);     // 31-35: deep-prefetch schedule (MID = 3)
+        case 32: return launch_cfg<128, 128, 2, 4, 32, 3>(p, st);
+        case 33: return launch_cfg<64, 128, 2, 4, 32, 3>(p, st);
+        case 34: return launch_cfg<128, 64, 4, 2, 32, 3>(p, st);
+        case 35: return launch_cfg<128, 32, 4, 1, 32, 3>(p, st);
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
         case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier
         case 22: return launch_cfg<128, 128, 2, 2, 32, 0, 2>(p, st);   // ablation: no barrier (racy, timing only)

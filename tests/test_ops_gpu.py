@@ -47,7 +47,7 @@ def test_conv2d_bias(ctx, C, K, H, W, k, s, p, d):
 
 
 # 0-4: register-staged tiles, plain schedule; 5-9: software-pipelined; 10-12: 8-wave; 13/15: BK 64/16; 16-19: LDS-DMA ring
-ALL_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+ALL_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 31, 32, 33, 34, 35]
 
 
 @pytest.mark.parametrize("tile", ALL_TILES)
