@@ -67,7 +67,7 @@ class Predictor(object):
             for k, v in max_data_shapes[0]:
                 shapes.setdefault(k, v)
         if "data" in shapes:
-            self._bind(tuple(shapes["data"])[2:])
+            self._bind(tuple(shapes["data"])[2:], tuple(shapes["data"])[0])
 
     # -- bind = lower + finalize --------------------------------------------------------------
     def _check_params(self, lw_sym, input_shapes):
@@ -87,19 +87,21 @@ class Predictor(object):
             if got != tuple(shp):
                 raise RuntimeError("shape inconsistent for %s inferred %s provided %s" % (name, shp, got))
 
-    def _bind(self, hw):
-        H, W = int(hw[0]), int(hw[1])
-        if (H, W) in self._plans:
-            return self._plans[(H, W)]
+    def _bind(self, hw, N=1):
+        """Static bind for (batch, H, W).  A batch > 1 stacks independent frames (one per clip): the convolutions run
+        with M = N*Ho*Wo, which is what fills the chip on the stride-16 layers."""
+        H, W, N = int(hw[0]), int(hw[1]), int(N)
+        if (N, H, W) in self._plans:
+            return self._plans[(N, H, W)]
         if H % 128 or W % 128:
             raise ValueError("image size %dx%d: the FlowNet encoder/decoder needs multiples of 128" % (H, W))
-        feat_shape = (1, 2048, 1, 1) if self._is_key else (1, 2048, H // 16, W // 16)
-        shapes = {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": feat_shape}
+        feat_shape = (N, 2048, 1, 1) if self._is_key else (N, 2048, H // 16, W // 16)
+        shapes = {"data": (N, 3, H, W), "data_key": (N, 3, H, W), "feat_key": feat_shape}
         shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}
         self._check_params(self._symbol, shapes)
         model = self._explicit_model
         if model is None:
-            model = shared_model(self._device_id, (H, W))
+            model = shared_model(self._device_id, (N, H, W))
         loaded = getattr(model, "_loaded_from", set())
         if id(self._arg_params) not in loaded:
             model.set_params(self._arg_params, self._aux_params)
@@ -124,15 +126,15 @@ class Predictor(object):
             role = "%s_%x" % (role, id(self) & 0xFFFFFF)
         plan = model.add_plan(role, text)
         plan.finalize()
-        self._plans[(H, W)] = (plan, lw, model)
-        return self._plans[(H, W)]
+        self._plans[(N, H, W)] = (plan, lw, model)
+        return self._plans[(N, H, W)]
 
     # -- forward ---------------------------------------------------------------------------------
     def predict(self, data_batch):
         arrays = dict(zip(self._data_names, data_batch.data[0]))
         data = arrays["data"]
-        H, W = tuple(data.shape)[2:]
-        plan, lw, m = self._bind((H, W))
+        N, _, H, W = tuple(data.shape)
+        plan, lw, m = self._bind((H, W), N)
         self._model = m
         # Host->HBM copies are the dominant cost of the reference's per-frame loop (25 MB fp32 per image).  The key
         # graph does not read `data_key`, and on non-key frames `data_key` is the previous call's `data` array
@@ -144,7 +146,7 @@ class Predictor(object):
             if res.get("data_key") != tag:
                 if res.get("data") == tag:
                     ptr, _ = m.buffer("data_key")
-                    m.read_device("data", ptr, 3 * H * W * 4)
+                    m.read_device("data", ptr, N * 3 * H * W * 4)
                 else:
                     m.write("data_key", _host(arrays["data_key"]))
                 res["data_key"] = tag
@@ -156,7 +158,7 @@ class Predictor(object):
             fk = arrays["feat_key"]
             ref = getattr(fk, "device_ref", None)
             if not (ref and ref[0] is m and ref[1] == "feat"):
-                self._upload_feat(_host(fk), H, W)
+                self._upload_feat(_host(fk), N, H, W)
         plan.run()
         out = {}
         for name in self.output_names:
@@ -164,38 +166,38 @@ class Predictor(object):
             if isinstance(d, str) and d.startswith("input:"):
                 out[name] = arrays[d[6:]]
             elif d == "logits":
-                out[name] = self._logits_handle(H, W)
+                out[name] = self._logits_handle(N, H, W)
             else:
-                out[name] = self._feat_handle(H, W)
+                out[name] = self._feat_handle(N, H, W)
         return [out]
 
-    def _logits_handle(self, H, W, ncls=19):
+    def _logits_handle(self, N, H, W, ncls=19):
         m = self._model
 
         def labels():
             # mx.ndarray.argmax returns float indices; the fused kernel wrote uint8 labels
-            return DeviceArray(shape=(1, H, W), fetch=lambda: m.read("labels", (1, H, W), np.uint8).astype(np.float32),
+            return DeviceArray(shape=(N, H, W), fetch=lambda: m.read("labels", (N, H, W), np.uint8).astype(np.float32),
                                device_ref=(m, "labels"))
-        return DeviceArray(shape=(1, ncls, H, W), fetch=lambda: m.read("logits", (1, ncls, H, W)),
+        return DeviceArray(shape=(N, ncls, H, W), fetch=lambda: m.read("logits", (N, ncls, H, W)),
                            device_ref=(m, "logits"), labels_of=labels)
 
-    def _feat_handle(self, H, W):
+    def _feat_handle(self, N, H, W):
         m = self._model
         h, w = H // 16, W // 16
 
         def fetch():
-            nhwc = m.read("feat", (h, w, 2048))
-            return np.ascontiguousarray(nhwc.transpose(2, 0, 1))[None]
-        return DeviceArray(shape=(1, 2048, h, w), fetch=fetch, device_ref=(m, "feat"))
+            nhwc = m.read("feat", (N, h, w, 2048))
+            return np.ascontiguousarray(nhwc.transpose(0, 3, 1, 2))
+        return DeviceArray(shape=(N, 2048, h, w), fetch=fetch, device_ref=(m, "feat"))
 
-    def _upload_feat(self, feat_nchw, H, W):
+    def _upload_feat(self, feat_nchw, N, H, W):
         f = np.asarray(feat_nchw, np.float32)
-        if f.shape != (1, 2048, H // 16, W // 16):
+        if f.shape != (N, 2048, H // 16, W // 16):
             raise ValueError("feat_key shape %s does not match the bound graph" % (f.shape,))
-        self._model.write("feat", np.ascontiguousarray(f[0].transpose(1, 2, 0)))
+        self._model.write("feat", np.ascontiguousarray(f.transpose(0, 2, 3, 1)))
 
-    def plan_for(self, H, W):
-        plan, lw, _ = self._bind((H, W))
+    def plan_for(self, H, W, N=1):
+        plan, lw, _ = self._bind((H, W), N)
         return plan, lw
 
 

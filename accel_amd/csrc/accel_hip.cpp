@@ -75,7 +75,7 @@ struct accel_model {
     std::map<std::string, DevBuf> pbufs;
     std::vector<accel_plan*> plans;
     std::map<std::string, accel_plan*> roles;
-    int feat_c = 0, feat_h = 0, feat_w = 0;     // shape of the propagated feature (`meta` line of the plans)
+    int feat_c = 0, feat_h = 0, feat_w = 0, feat_n = 1;   // shape of the propagated feature (`meta` line of the plans)
     // derived persistent buffers (`pbuf name=featG from=feat`): a linear image of another buffer that the plans keep
     // in step with it.  Writing the source from outside a plan that also writes the derived buffer makes it stale; a
     // plan that reads a stale derived buffer first runs the model's `init:<name>` plan (see accel_plan_run).
@@ -90,8 +90,10 @@ struct BufRef {
     std::string space;
     size_t off = 0;
     int C = 0, Cs = 0, H = 0, W = 0;
+    int N = 1;              // images in the batch; image n starts n*H*W pixels (n*H*W*Cs floats) after image 0
     bool set = false;
     float* ptr = nullptr;   // resolved at finalize
+    size_t img() const { return (size_t)H * W * Cs; }   // floats per image
 };
 
 typedef std::map<std::string, std::string> KV;
@@ -180,10 +182,12 @@ static int parse_buf(const KV& kv, const char* key, BufRef& r)
     std::stringstream ss(it->second);
     std::string tok;
     while (std::getline(ss, tok, ':')) f.push_back(tok);
-    if (f.size() != 6) return fail(ACCEL_ERR_PLAN, "bad buffer reference %s=%s", key, it->second.c_str());
+    if (f.size() != 6 && f.size() != 7) return fail(ACCEL_ERR_PLAN, "bad buffer reference %s=%s", key, it->second.c_str());
     r.space = f[0];
     r.off = strtoull(f[1].c_str(), nullptr, 10);
     r.C = atoi(f[2].c_str()); r.Cs = atoi(f[3].c_str()); r.H = atoi(f[4].c_str()); r.W = atoi(f[5].c_str());
+    r.N = f.size() == 7 ? atoi(f[6].c_str()) : 1;
+    if (r.N < 1) return fail(ACCEL_ERR_PLAN, "bad batch size in %s=%s", key, it->second.c_str());
     r.set = true;
     return 0;
 }
@@ -254,7 +258,7 @@ static int parse_plan(accel_plan* p, const char* text)
             continue;
         }
         if (kind == "meta") {
-            if (kv_has(kv, "feat_c")) { p->m->feat_c = (int)kv_int(kv, "feat_c"); p->m->feat_h = (int)kv_int(kv, "feat_h"); p->m->feat_w = (int)kv_int(kv, "feat_w"); }
+            if (kv_has(kv, "feat_c")) { p->m->feat_c = (int)kv_int(kv, "feat_c"); p->m->feat_h = (int)kv_int(kv, "feat_h"); p->m->feat_w = (int)kv_int(kv, "feat_w"); p->m->feat_n = (int)kv_int(kv, "feat_n", 1); }
             continue;
         }
         if (kind == "arena") { p->arena_bytes = strtoull(kv_str(kv, "bytes", "0").c_str(), nullptr, 10); continue; }
@@ -318,10 +322,8 @@ static int resolve(accel_plan* p, BufRef& r, const char* what)
 {
     if (!r.set) return fail(ACCEL_ERR_PLAN, "missing buffer '%s'", what);
     if (r.space == "A") {
-        const size_t need = r.off + (size_t)r.H * r.W * r.Cs * sizeof(float);
         // a view's last pixel row may stop short of Cs; be lenient by C
-        const size_t need_min = r.off + ((size_t)(r.H * r.W - 1) * r.Cs + r.C) * sizeof(float);
-        (void)need;
+        const size_t need_min = r.off + (((size_t)r.N * r.H * r.W - 1) * r.Cs + r.C) * sizeof(float);
         if (need_min > p->arena_bytes) return fail(ACCEL_ERR_PLAN, "buffer '%s' exceeds arena (%zu > %zu)", what, need_min, p->arena_bytes);
         r.ptr = reinterpret_cast<float*>(p->arena + r.off);
     } else {
@@ -491,10 +493,16 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.y = op.b.ptr; c.yCs = op.b.Cs;
     if (op.d.set) { c.res = op.d.ptr; c.resCs = op.d.Cs; }
     c.Cout_store = cout_store;
-    c.M = c.Ho * c.Wo;
+    // batch: the GEMM M dimension runs over (n, oy, ox); images are stacked pixel-major in every view
+    if (op.b.N != op.a.N || (op.c.set && op.c.N != op.a.N) || (op.d.set && op.d.N != op.a.N))
+        return fail(ACCEL_ERR_PLAN, "conv %s: batch sizes of the views differ", op.name.c_str());
+    c.M = op.a.N * c.Ho * c.Wo;
     auto extent = [](const BufRef& r, int cuse) {
-        return (unsigned)((((size_t)r.H * r.W - 1) * r.Cs + cuse) * sizeof(float));
+        const size_t b = (((size_t)r.N * r.H * r.W - 1) * r.Cs + cuse) * sizeof(float);
+        return (unsigned)(b > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b);
     };
+    if ((size_t)op.a.N * op.a.img() * 4 > 0xFFFFFFF0ull || (size_t)op.b.N * op.b.img() * 4 > 0xFFFFFFF0ull)
+        return fail(ACCEL_ERR_PLAN, "conv %s: a batched view exceeds the 4 GiB a buffer resource can address", op.name.c_str());
     c.x_bytes = extent(op.a, c.Cin > op.a.Cs ? op.a.Cs : c.Cin);
     c.y_bytes = extent(op.b, cout_store);
     if (op.c.set) c.y2_bytes = extent(op.c, cout_store);
@@ -662,7 +670,7 @@ static int finalize_op(accel_plan* p, Op& op)
             if (uniform) {
                 const int zCs = roundup(q.ncls, 4);
                 void* z = nullptr;
-                std::vector<float> zeros((size_t)q.Hs * q.Ws * zCs, 0.f);
+                std::vector<float> zeros((size_t)op.a.N * q.Hs * q.Ws * zCs, 0.f);
                 if ((rc = dev_upload(p, zeros.data(), zeros.size() * sizeof(float), &z))) return rc;
                 op.tail_z = static_cast<float*>(z);
                 op.tail_lowres = q;
@@ -676,7 +684,7 @@ static int finalize_op(accel_plan* p, Op& op)
     case OP_COPY: {
         if ((rc = parse_buf(kv, "src", op.a)) || (rc = parse_buf(kv, "dst", op.b))) return rc;
         if ((rc = resolve(p, op.a, "src")) || (rc = resolve(p, op.b, "dst"))) return rc;
-        if (op.a.H != op.b.H || op.a.W != op.b.W || op.a.C != op.b.C) return fail(ACCEL_ERR_PLAN, "copy: view shapes differ");
+        if (op.a.H != op.b.H || op.a.W != op.b.W || op.a.C != op.b.C || op.a.N != op.b.N) return fail(ACCEL_ERR_PLAN, "copy: view shapes differ");
         return 0;
     }
     case OP_EXPORT_NCHW:
@@ -695,22 +703,60 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     hipError_t e = hipSuccess;
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
-    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, st); break;
-    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, st); break;
-    case OP_POOL: e = launch_pool(op.pool, st); break;
-    case OP_WARP: e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W,
-                                       op.d.set ? op.d.ptr : nullptr, op.d.Cs, op.p0, st); break;
-    case OP_DCN_COLS: e = launch_dcn_cols(op.dcn, st); break;
-    case OP_SCORE_TAIL:
-        if (op.tail_z) {
-            e = launch_score_fuse_lowres(op.tail.left, op.tail.lCs, op.tail.right, op.tail.rCs, op.tail.cw, op.tail_z,
-                                         op.tail_lowres.lCs, op.tail.ncls, op.tail.Hs * op.tail.Ws, st);
-            if (e == hipSuccess) e = launch_score_tail(op.tail_lowres, st);
-        } else e = launch_score_tail(op.tail, st);
+    // the byte movers run once per image of the batch (pointer offsets; a few us each), only the convolution is
+    // batched inside the kernel -- that is where the larger M pays
+    case OP_PREP_RGB:
+        for (int n = 0; n < op.b.N && e == hipSuccess; ++n)
+            e = launch_prep_rgb(op.a.ptr + (size_t)n * 3 * op.H * op.W, op.b.ptr + n * op.b.img(), op.H, op.W, op.p0, op.p1, st);
         break;
-    case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.H * op.a.W, st); break;
-    case OP_EXPORT_NCHW: e = launch_nhwc_to_nchw(op.a.ptr, op.a.Cs, op.b.ptr, op.a.C, op.a.H, op.a.W, st); break;
-    case OP_IMPORT_NCHW: e = launch_nchw_to_nhwc(op.a.ptr, op.b.ptr, op.b.Cs, op.b.C, op.b.H, op.b.W, st); break;
+    case OP_PREP_FLOW:
+        for (int n = 0; n < op.c.N && e == hipSuccess; ++n)
+            e = launch_prep_flow(op.a.ptr + (size_t)n * 3 * op.H * op.W, op.b.ptr + (size_t)n * 3 * op.H * op.W,
+                                 op.c.ptr + n * op.c.img(), op.H, op.W, st);
+        break;
+    case OP_POOL:
+        for (int n = 0; n < op.a.N && e == hipSuccess; ++n) {
+            PoolParams q = op.pool;
+            q.x += n * op.a.img(); q.y += n * op.b.img();
+            e = launch_pool(q, st);
+        }
+        break;
+    case OP_WARP:
+        for (int n = 0; n < op.a.N && e == hipSuccess; ++n)
+            e = launch_flow_warp(op.a.ptr + n * op.a.img(), op.a.Cs, op.b.ptr + n * op.b.img(), op.b.Cs, op.c.ptr + n * op.c.img(), op.c.Cs,
+                                 op.a.C, op.a.H, op.a.W, op.d.set ? op.d.ptr + n * op.d.img() : nullptr, op.d.Cs, op.p0, st);
+        break;
+    case OP_DCN_COLS:
+        for (int n = 0; n < op.a.N && e == hipSuccess; ++n) {
+            DcnColsParams q = op.dcn;
+            q.x += n * op.a.img(); q.off += n * op.b.img(); q.col += n * op.c.img();
+            e = launch_dcn_cols(q, st);
+        }
+        break;
+    case OP_SCORE_TAIL: {
+        const int N = op.a.N;
+        if (op.tail_z)     // low-resolution fusion is pixel-wise: one launch over all images
+            e = launch_score_fuse_lowres(op.tail.left, op.tail.lCs, op.tail.right, op.tail.rCs, op.tail.cw, op.tail_z,
+                                         op.tail_lowres.lCs, op.tail.ncls, N * op.tail.Hs * op.tail.Ws, st);
+        for (int n = 0; n < N && e == hipSuccess; ++n) {
+            ScoreTailParams q = op.tail_z ? op.tail_lowres : op.tail;
+            q.left += (size_t)n * q.Hs * q.Ws * q.lCs;
+            if (q.right) q.right += (size_t)n * q.Hs * q.Ws * q.rCs;
+            q.logits += (size_t)n * q.ncls * q.H * q.W;
+            q.labels += (size_t)n * q.H * q.W;
+            e = launch_score_tail(q, st);
+        }
+        break;
+    }
+    case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.N * op.a.H * op.a.W, st); break;
+    case OP_EXPORT_NCHW:
+        for (int n = 0; n < op.a.N && e == hipSuccess; ++n)
+            e = launch_nhwc_to_nchw(op.a.ptr + n * op.a.img(), op.a.Cs, op.b.ptr + (size_t)n * op.a.C * op.a.H * op.a.W, op.a.C, op.a.H, op.a.W, st);
+        break;
+    case OP_IMPORT_NCHW:
+        for (int n = 0; n < op.b.N && e == hipSuccess; ++n)
+            e = launch_nchw_to_nhwc(op.a.ptr + (size_t)n * op.b.C * op.b.H * op.b.W, op.b.ptr + n * op.b.img(), op.b.Cs, op.b.C, op.b.H, op.b.W, st);
+        break;
     }
     if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "launch of op %s (%s) failed: %s", op.kind_name.c_str(), op.name.c_str(), hipGetErrorString(e));
     return 0;
@@ -851,7 +897,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16, c.ph * 16 + c.pw};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16, c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {
@@ -1170,15 +1216,19 @@ static int frame_outputs(accel_model* m, float* feat_out, float* logits_out, uin
         // `feat` lives NHWC in HBM; the boundary layout is NCHW (res5c_relu_output / warping_feat_output)
         auto src = m->pbufs.find("feat");
         if (src == m->pbufs.end() || !m->feat_c) return fail(ACCEL_ERR_ARG, "feat_out requested but the model has no propagated feature");
-        const size_t bytes = (size_t)m->feat_c * m->feat_h * m->feat_w * sizeof(float);
+        const size_t img = (size_t)m->feat_c * m->feat_h * m->feat_w;
+        const size_t bytes = img * m->feat_n * sizeof(float);
         DevBuf& tmp = m->pbufs["feat_nchw"];
-        if (!tmp.ptr) {
+        if (!tmp.ptr || tmp.bytes < bytes) {
+            if (tmp.ptr) hipFree(tmp.ptr);
             if (hipMalloc(&tmp.ptr, bytes) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipMalloc(feat_nchw) failed");
             tmp.bytes = bytes;
         }
-        hipError_t e = launch_nhwc_to_nchw(static_cast<const float*>(src->second.ptr), m->feat_c, static_cast<float*>(tmp.ptr),
-                                           m->feat_c, m->feat_h, m->feat_w, m->ctx->stream);
-        if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "feature export failed: %s", hipGetErrorString(e));
+        for (int n = 0; n < m->feat_n; ++n) {
+            hipError_t e = launch_nhwc_to_nchw(static_cast<const float*>(src->second.ptr) + n * img, m->feat_c,
+                                               static_cast<float*>(tmp.ptr) + n * img, m->feat_c, m->feat_h, m->feat_w, m->ctx->stream);
+            if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "feature export failed: %s", hipGetErrorString(e));
+        }
         if ((rc = accel_model_read(m, "feat_nchw", feat_out, bytes, on_dev))) return rc;
     }
     if (logits_out && (rc = accel_model_read(m, "logits", logits_out, pbuf_bytes(m, "logits"), on_dev))) return rc;

@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= p.M) return;
-    const int oy = m / p.Wo, ox = m - oy * p.Wo;
+    const int HoWo = p.Ho * p.Wo;
+    const int n = m / HoWo, rem = m - n * HoWo;             // batched: image n, pixel (oy, ox)
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const float* xn = p.x + (size_t)n * p.H * p.W * p.xCs;
     const int C4 = p.Cin / 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int ky = 0; ky < p.kh; ++ky) {
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
         for (int kx = 0; kx < p.kw; ++kx) {
             const int ix = ox * p.sw - p.pw + kx * p.dw;
             if ((unsigned)ix >= (unsigned)p.W) continue;
-            const float4* xp = reinterpret_cast<const float4*>(p.x + ((size_t)iy * p.W + ix) * p.xCs);
+            const float4* xp = reinterpret_cast<const float4*>(xn + ((size_t)iy * p.W + ix) * p.xCs);
             const float4* wp = reinterpret_cast<const float4*>(p.w + (size_t)(ky * p.kw + kx) * p.Cin);
             const size_t rs = (size_t)p.K_pad / 4;
             for (int c = lane; c < C4; c += 64) {

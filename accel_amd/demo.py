@@ -79,14 +79,15 @@ class ClipRunner(object):
 
     data_names = ['data', 'data_key', 'feat_key']
 
-    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None, model=None):
+    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None, model=None, batch=1):
         self.version = str(version)
         self.cfg = cfg
         H, W = frame_hw
         _, key_sym, cur_sym = get_symbols(version, cfg)
         ctx = context or [mx.gpu(0)]
-        max_shape = [[('data', (1, 3, H, W)), ('data_key', (1, 3, H, W))]]
-        provide = [[('data', (1, 3, H, W)), ('data_key', (1, 3, H, W)), ('feat_key', (1, 2048, 1, 1))]]
+        B = int(batch)      # frames per call: one frame of each of B independent clips (throughput mode)
+        max_shape = [[('data', (B, 3, H, W)), ('data_key', (B, 3, H, W))]]
+        provide = [[('data', (B, 3, H, W)), ('data_key', (B, 3, H, W)), ('feat_key', (B, 2048, 1, 1))]]
         self.key_predictor = Predictor(key_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
                                        provide_data=provide, provide_label=[None],
                                        arg_params=arg_params, aux_params=aux_params, model=model)

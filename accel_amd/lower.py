@@ -38,15 +38,15 @@ def _r4(c):
 class VBuf(object):
     """A physical buffer: arena slot (offset assigned later) or persistent."""
 
-    def __init__(self, bid, Cs, H, W, space="A"):
-        self.id, self.Cs, self.H, self.W, self.space = bid, Cs, H, W, space
+    def __init__(self, bid, Cs, H, W, space="A", N=1):
+        self.id, self.Cs, self.H, self.W, self.space, self.N = bid, Cs, H, W, space, N
         self.first, self.last = None, None
         self.off = 0
         self.streams = set()
 
     @property
     def nbytes(self):
-        return self.H * self.W * self.Cs * 4
+        return self.N * self.H * self.W * self.Cs * 4
 
     def touch(self, op_idx):
         if self.first is None:
@@ -67,8 +67,9 @@ class View(object):
         return self.buf.W
 
     def ref(self):
-        return "%s:%d:%d:%d:%d:%d" % (self.buf.space, self.buf.off + self.coff * 4, self.C,
-                                      self.buf.Cs, self.buf.H, self.buf.W)
+        r = "%s:%d:%d:%d:%d:%d" % (self.buf.space, self.buf.off + self.coff * 4, self.C,
+                                   self.buf.Cs, self.buf.H, self.buf.W)
+        return r if self.buf.N == 1 else r + ":%d" % self.buf.N     # batch: images stacked pixel-major
 
 
 class Lowering(object):
@@ -115,9 +116,10 @@ class Lowering(object):
         self.cur_stream = 0
         self.last_writer = {}   # buffer key -> (op index, stream)
         data_shape = input_shapes["data"]
-        self.H, self.W = int(data_shape[2]), int(data_shape[3])
+        self.N, self.H, self.W = int(data_shape[0]), int(data_shape[2]), int(data_shape[3])
+        self.nsfx = "" if self.N == 1 else ":%d" % self.N     # batch suffix of literal buffer references
         for name in ("data", "data_key"):
-            self.pbufs[name] = 3 * self.H * self.W * 4
+            self.pbufs[name] = self.N * 3 * self.H * self.W * 4
 
     # ---- helpers ---------------------------------------------------------------
     def shape(self, n):
@@ -127,14 +129,14 @@ class Lowering(object):
         return self.cons.get(id(n), [])
 
     def new_buf(self, C, H, W, Cs=None):
-        b = VBuf(len(self.bufs), Cs or _r4(C), H, W)
+        b = VBuf(len(self.bufs), Cs or _r4(C), H, W, N=self.N)
         self.bufs.append(b)
         return b
 
     def pbuf_view(self, name, C, H, W, Cs=None):
         Cs = Cs or _r4(C)
-        b = VBuf(-1, Cs, H, W, space=name)
-        self.pbufs[name] = max(self.pbufs.get(name, 0), H * W * Cs * 4)
+        b = VBuf(-1, Cs, H, W, space=name, N=self.N)
+        self.pbufs[name] = max(self.pbufs.get(name, 0), self.N * H * W * Cs * 4)
         return View(b, C)
 
     def _head_on_feature(self, conv, feature):
@@ -156,7 +158,7 @@ class Lowering(object):
         """The derived persistent buffer featG = W_conv * feat (no bias), kept in step with `feat` by the plans."""
         _, cin, _, _ = self.shape(conv.inputs[0])
         v = self.pbuf_view("featG", C, H, W)
-        self.derived_bufs["featG"] = {"from": "feat", "w": conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W}
+        self.derived_bufs["featG"] = {"from": "feat", "w": conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W, "N": self.N}
         return v
 
     def dest_for(self, node):
@@ -172,7 +174,7 @@ class Lowering(object):
     def _bkey(v):
         return ("A", v.buf.id) if v.buf.space == "A" else ("P", v.buf.space)
 
-    def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0):
+    def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0, nbytes_fixed=0.0):
         idx = len(self.ops)
         for v in list(reads) + list(writes):
             if v is not None and v.buf.space == "A":
@@ -196,6 +198,7 @@ class Lowering(object):
             args["stream"] = st
             if waits:
                 args["wait"] = ",".join(str(w) for w in sorted(waits))
+        flops, nbytes = flops * self.N, nbytes * self.N + nbytes_fixed     # callers give per-image work (+ weights, read once)
         if flops:
             args["flops"] = "%.6g" % flops
             self.total_flops += flops
@@ -233,7 +236,7 @@ class Lowering(object):
         if key in self.val:
             return self.val[key]
         v = View(self.new_buf(3, self.H, self.W), 3)
-        args = {"src": "%s:0:3:4:%d:%d" % (var.name, self.H, self.W), "dst": v, "H": self.H, "W": self.W}
+        args = {"src": "%s:0:3:4:%d:%d%s" % (var.name, self.H, self.W, self.nsfx), "dst": v, "H": self.H, "W": self.W}
         if bn is not None:
             args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
         self.emit("prep_rgb", args, [], [v], nbytes=(12 + 16) * self.H * self.W)
@@ -408,8 +411,8 @@ class Lowering(object):
         kk = a["kernel"][0] * a["kernel"][1]
         in_elems = ho * wo * kk * _r4(cin) if op == "DeformableConvolution" else hi * wi * cin
         w_elems = cout * cin * (16 if mode == "deconv2x" else kk)
-        nbytes = 4.0 * (in_elems + w_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
-        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes)
+        nbytes = 4.0 * (in_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
+        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes, nbytes_fixed=4.0 * w_elems)
         self.absorbed.add(id(A))
         if feat_image is not None:
             out, out2 = out2, None     # the graph value of the chain is the biased, activated copy
@@ -478,8 +481,8 @@ class Lowering(object):
             self.absorbed.add(id(d))
         self.absorbed.add(id(cat))
         out = View(self.new_buf(6, self.H // 2, self.W // 2, Cs=8), 6)
-        self.emit("prep_flow", {"cur": "%s:0:3:4:%d:%d" % (srcs[0], self.H, self.W),
-                                "prev": "%s:0:3:4:%d:%d" % (srcs[1], self.H, self.W),
+        self.emit("prep_flow", {"cur": "%s:0:3:4:%d:%d%s" % (srcs[0], self.H, self.W, self.nsfx),
+                                "prev": "%s:0:3:4:%d:%d%s" % (srcs[1], self.H, self.W, self.nsfx),
                                 "dst": out, "H": self.H, "W": self.W}, [], [out],
                   nbytes=24.0 * self.H * self.W + 8.0 * self.H * self.W)
         self.absorbed.add(id(P))
@@ -554,12 +557,13 @@ class Lowering(object):
             raise NotImplementedError("unsupported score tail at %s" % node.name)
         ncls = ups[0].attrs["num_filter"]
         logits = self.pbuf_view("logits", ncls, self.H, self.W, Cs=4)
-        self.pbufs["logits"] = ncls * self.H * self.W * 4
+        self.pbufs["logits"] = self.N * ncls * self.H * self.W * 4
         labels = self.pbuf_view("labels", 1, self.H, self.W, Cs=4)
-        self.pbufs["labels"] = (self.H * self.W + 255) // 256 * 256
+        self.pbufs["labels"] = (self.N * self.H * self.W + 255) // 256 * 256
         left = self.input_view(ups[0].inputs[0])
         args = {"name": node.name, "left": left, "wl": ups[0].inputs[1].name, "H": self.H, "W": self.W, "ncls": ncls,
-                "logits": "logits:0:%d:4:%d:%d" % (ncls, self.H, self.W), "labels": "labels:0:1:4:%d:%d" % (self.H, self.W)}
+                "logits": "logits:0:%d:4:%d:%d%s" % (ncls, self.H, self.W, self.nsfx),
+                "labels": "labels:0:1:4:%d:%d%s" % (self.H, self.W, self.nsfx)}
         reads = [left]
         flops = 0.0
         if corr is not None:
@@ -665,7 +669,7 @@ class Lowering(object):
             lines.append("option dtype=f16")   # convolutions on the fp16 matrix cores (fp32 storage + accumulate)
         elif conv_dtype != "f32":
             raise ValueError("conv_dtype must be 'f32' or 'f16'")
-        lines.append("meta feat_c=2048 feat_h=%d feat_w=%d" % (self.H // 16, self.W // 16))
+        lines.append("meta feat_c=2048 feat_h=%d feat_w=%d feat_n=%d" % (self.H // 16, self.W // 16, self.N))
         lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
         for name, nbytes in sorted(self.pbufs.items()):
             src = self.derived_bufs.get(name, {}).get("from")
@@ -707,16 +711,17 @@ def fold_params(derived, params):
 def init_plan_text(name, d):
     """Plan of role `init:<name>` that rebuilds a derived persistent buffer from its source (run by
     accel_plan_run when a plan reads the buffer while it is stale, e.g. after a host upload of `feat`)."""
-    H, W, cin, cout = d["H"], d["W"], d["cin"], d["cout"]
+    H, W, cin, cout, N = d["H"], d["W"], d["cin"], d["cout"], d.get("N", 1)
+    sfx = "" if N == 1 else ":%d" % N
     return "\n".join([
         "# accel_amd plan: rebuild %s = %s * %s" % (name, d["w"], d["from"]),
         "option graph=0",
         "arena bytes=%d" % ALIGN,
-        "pbuf name=%s bytes=%d" % (d["from"], H * W * _r4(cin) * 4),
-        "pbuf name=%s bytes=%d from=%s" % (name, H * W * _r4(cout) * 4, d["from"]),
-        "conv name=init_%s out=%s:0:%d:%d:%d:%d w=%s act=0 slope=0.1 cin=%d cout=%d mode=conv in=%s:0:%d:%d:%d:%d "
-        "k=1,1 s=1,1 p=0,0 d=1,1 flops=%g" % (name, name, cout, _r4(cout), H, W, d["w"], cin, cout,
-                                           d["from"], cin, _r4(cin), H, W, 2.0 * H * W * cin * cout)]) + "\n"
+        "pbuf name=%s bytes=%d" % (d["from"], N * H * W * _r4(cin) * 4),
+        "pbuf name=%s bytes=%d from=%s" % (name, N * H * W * _r4(cout) * 4, d["from"]),
+        "conv name=init_%s out=%s:0:%d:%d:%d:%d%s w=%s act=0 slope=0.1 cin=%d cout=%d mode=conv in=%s:0:%d:%d:%d:%d%s "
+        "k=1,1 s=1,1 p=0,0 d=1,1 flops=%g" % (name, name, cout, _r4(cout), H, W, sfx, d["w"], cin, cout,
+                                           d["from"], cin, _r4(cin), H, W, sfx, 2.0 * N * H * W * cin * cout)]) + "\n"
 
 
 def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True):

@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--interval", type=int, default=5)
     ap.add_argument("--gather", default="logits", choices=["logits", "labels", "none"])
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "4")),
+                    help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
+                         "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ACCEL_BENCH_LANES", "1")),
                     help="independent clip pipelines per GPU (own model, buffers and streams each)")
     ap.add_argument("--dtype", default=os.environ.get("ACCEL_CONV_DTYPE", "f32"), choices=["f32", "f16"],
@@ -110,6 +113,7 @@ def _run(a):
     if world != a.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, a.gpus))
     H, W = [int(v) for v in a.size.split("x")]
+    B = max(1, a.batch)
 
     import torch
     if not torch.cuda.is_available():
@@ -139,27 +143,27 @@ def _run(a):
     lanes = []
     for l in range(max(1, a.lanes)):
         model = runtime.Model(runtime.Context(local_rank))
-        runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)], model=model)
-        key_plan, _ = runner.key_predictor.plan_for(H, W)
-        cur_plan, _ = runner.cur_predictor.plan_for(H, W)
+        runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)], model=model, batch=B)
+        key_plan, _ = runner.key_predictor.plan_for(H, W, B)
+        cur_plan, _ = runner.cur_predictor.plan_for(H, W, B)
         lanes.append({"model": model, "key": key_plan, "cur": cur_plan, "gather": None, "rot": (l * a.interval) // max(1, a.lanes)})
     del arg, aux
     model, key_plan, cur_plan = lanes[0]["model"], lanes[0]["key"], lanes[0]["cur"]
 
-    # one clip per step and lane, distinct per rank, resident in HBM
-    frames = synth.make_clip(H, W, a.interval, seed=20260929 + rank)
-    dev_frames = [torch.from_numpy(image.transform(f, config.network.PIXEL_MEANS).astype(np.float32)).cuda()
-                  for f in frames]
-    nbytes = 3 * H * W * 4
+    # B clips per step and lane, distinct per rank and clip, resident in HBM: dev_frames[t] = frame t of every clip
+    clips = [synth.make_clip(H, W, a.interval, seed=20260929 + rank * 64 + b) for b in range(B)]
+    dev_frames = [torch.from_numpy(np.concatenate([image.transform(c[t], config.network.PIXEL_MEANS).astype(np.float32) for c in clips], axis=0)).cuda()
+                  for t in range(a.interval)]
+    nbytes = B * 3 * H * W * 4
 
     gather_note = "none (single GPU)"
     if (world > 1 or force_dist) and a.gather != "none":
         try:
             for ln in lanes:
                 if a.gather == "logits":
-                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "logits", (19, H, W), "f4", local_rank)
+                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "logits", (B, 19, H, W), "f4", local_rank)
                 else:
-                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "labels", (H, W), "u1", local_rank)
+                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "labels", (B, H, W), "u1", local_rank)
             gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered" % a.gather
         except Exception as e:   # keep the bench alive; the JSON says what happened
             for ln in lanes:
@@ -208,7 +212,7 @@ def _run(a):
 
     out = None
     if rank == 0:
-        frames_total = world * a.steps * a.interval * len(lanes)
+        frames_total = world * a.steps * a.interval * len(lanes) * B
         value = frames_total / elapsed
         out = {"metric": "frames/sec 1024x2048 Accel-%s kf=%d" % (a.version, a.interval), "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -218,9 +222,10 @@ def _run(a):
                "dtype": "f32" if a.dtype == "f32" else "f16 operands on the matrix cores, f32 storage + accumulate (reduced precision: not the headline)",
                "data": "synthetic",
                "config": {"workload": "Accel-%s (R101-DCN key branch + FlowNet-S warp + R%s correction branch + fused score tail), "
-                                      "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step"
-                                      % (a.version, a.version, H, W, a.interval, len(lanes), a.interval - 1),
-                          "frames_per_step_per_gpu": a.interval * len(lanes), "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
+                                      "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step, "
+                                      "processed %d clips at a time (batched frames of independent clips)"
+                                      % (a.version, a.version, H, W, a.interval, len(lanes) * B, a.interval - 1, B),
+                          "frames_per_step_per_gpu": a.interval * len(lanes) * B, "clips_per_call": B, "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
                           "gather": gather_note, "weights": "seeded random",
                           "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
                                        "taken from the warped W_fc6*feat image of the key frame" if os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
@@ -247,14 +252,17 @@ def _run(a):
         if os.path.exists(tj) and a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32" and len(lanes) == 1:
             with open(tj) as f:
                 tr = json.load(f)
+        else:
+            tr = None
+        if tr is not None and int(tr.get("batch", 1)) == B:
             traffic = round(tr["read_bytes_per_launch"] + tr["write_bytes_per_launch"])
             traffic_note = "bytes per launch, profiles/r01_pmc_traffic.json: " + tr["method"]
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                            "algorithmic_bytes_per_launch": round(by / n),
-                           "kernel": "conv_igemm_f32_kernel (all tile variants)", "launches_per_clip": int(n),
+                           "kernel": "conv_igemm_f32_kernel (all tile variants)", "launches_per_step": int(n),
                            "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
-                           "conv_ms_per_clip": round(ms, 3), "all_kernels_ms_per_clip": round(clip_ms, 3)}
+                           "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.version, a.interval)
     def finish():

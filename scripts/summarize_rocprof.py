@@ -68,7 +68,8 @@ def main():
         nr = sum(n for k, n in nf.items() if fam in k)
         ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if fam in k) * 1024
         nwr = sum(n for k, n in nw.items() if fam in k)
-        json.dump({"kernel": fam + " (all tile variants)", "read_bytes_per_launch": rd / max(nr, 1),
+        extra = dict(a.split("=", 1) for a in sys.argv[6:] if "=" in a)      # e.g. batch=4: the workload the passes ran
+        json.dump({"kernel": fam + " (all tile variants)", "batch": int(extra.get("batch", 1)), "read_bytes_per_launch": rd / max(nr, 1),
                    "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr,
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 8 "
                              "--warmup 2 --no-cpu-baseline`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "

@@ -304,3 +304,40 @@ def test_resident_input_reuse_is_invisible(demo_cfg):
         np.testing.assert_array_equal(c, d)
     finally:
         tester.release_models()
+
+
+@pytest.mark.parametrize("version", ["18", "101"])
+def test_batched_clips_match_single_clip_runs(demo_cfg, version):
+    """Throughput mode: every call runs one frame of each of B independent clips (arrays with a leading batch of B).
+    Image b of the batched run must reproduce the batch-1 run of clip b (same kernels, other tile choices: compared
+    at 1e-4 of the logit range; labels identical outside the tie band) -- over a key frame and two non-key frames, so
+    the per-image feature / featG hand-off is covered too."""
+    from accel_amd import demo, mx
+    from accel_amd.core import tester
+    H, W, B, interval = 128, 256, 3, 3
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params(version, H, W, demo_cfg)
+    clips = [synth.make_clip(H, W, interval, seed=77 + b) for b in range(B)]
+    per_clip = [demo.build_batches(c, demo_cfg) for c in clips]
+    try:
+        single = []
+        for b in range(B):
+            r = demo.ClipRunner(version, demo_cfg, arg, aux, (H, W))
+            single.append([r.step(t, per_clip[b][t], interval)[0].asnumpy().copy() for t in range(interval)])
+        tester.release_models()
+        rb = demo.ClipRunner(version, demo_cfg, arg, aux, (H, W), batch=B)
+        for t in range(interval):
+            arrays = [mx.nd.array(np.concatenate([per_clip[b][t][i].asnumpy() for b in range(B)], axis=0)) for i in range(2)]
+            arrays.append(mx.nd.array(np.zeros((B, 2048, 1, 1), np.float32)))
+            logits, labels = rb.step(t, arrays, interval)
+            lg, lab = logits.asnumpy(), labels.asnumpy()
+            assert lg.shape == (B, 19, H, W) and lab.shape == (B, H, W)
+            for b in range(B):
+                ref = single[b][t][0]
+                tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+                assert float(np.abs(lg[b] - ref).max()) <= tol, (version, t, b, float(np.abs(lg[b] - ref).max()), tol)
+                srt = np.sort(ref, axis=0)
+                safe = (srt[-1] - srt[-2]) > 2 * tol
+                np.testing.assert_array_equal(lab[b][safe], np.argmax(ref, axis=0)[safe])
+    finally:
+        tester.release_models()
