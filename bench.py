@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--interval", type=int, default=5)
     ap.add_argument("--gather", default="logits", choices=["logits", "labels", "none"])
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "4")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "8")),
                     help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
                          "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("ACCEL_BENCH_LANES", "1")),

@@ -7,12 +7,13 @@ from accel_amd.core import tester
 from accel_amd.utils import synth
 update_config(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'tests', 'golden', 'dff_deeplab_vid_demo.yaml'))
 ver = sys.argv[1] if len(sys.argv) > 1 else '18'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 H, W = 1024, 2048
 config.SCALES[0] = (H, W)
 arg, aux = synth.model_params(ver, H, W, config)
-runner = demo.ClipRunner(ver, config, arg, aux, (H, W))
+runner = demo.ClipRunner(ver, config, arg, aux, (H, W), batch=B)
 for nm, pred in (('key', runner.key_predictor), ('cur', runner.cur_predictor)):
-    plan, lw = pred.plan_for(H, W)
+    plan, lw = pred.plan_for(H, W, B)
     ms = plan.profile(3)
     ops = plan.ops()
     tot = ms.sum()
