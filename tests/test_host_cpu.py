@@ -418,3 +418,26 @@ def test_cityscape_layout_palette_and_miou(tmp_path):
     assert info["IU_array"][3] > 0 and info["IU_array"][[c for c in present if c != 3]].sum() == 0
     cm = confusion_matrix(np.array([0, 1, 1, 2]), np.array([0, 1, 2, 2]), 3)
     assert cm.tolist() == [[1, 0, 0], [0, 1, 1], [0, 0, 1]]
+
+
+def test_batched_lowering_scales_buffers_and_work(demo_cfg):
+    """A leading batch of B frames (one per independent clip): every buffer reference carries `:B`, persistent buffers
+    and the arena grow B-fold, per-op flops grow B-fold while weight bytes are counted once."""
+    from accel_amd import lower
+    from accel_amd.config.config import config
+    inst = _sym("18")
+    sym = inst.get_cur_test_symbol(config)
+    sh1 = _shapes(128, 256, False)
+    shB = {k: (3,) + tuple(v[1:]) for k, v in sh1.items()}
+    t1, l1 = lower.lower(sym, sh1)
+    tB, lB = lower.lower(sym, shB)
+    assert abs(lB.total_flops - 3 * l1.total_flops) < 1e-6 * lB.total_flops
+    assert lB.arena_bytes >= 3 * l1.arena_bytes - 3 * 256 * len(l1.bufs)
+    for name, n1 in l1.pbufs.items():
+        assert lB.pbufs[name] >= 3 * n1 - 256, name
+    refs = re.findall(r"=([A-Za-z_]\w*:\d+:\d+:\d+:\d+:\d+(?::\d+)?)", tB)
+    assert refs and all(r.endswith(":3") for r in refs), [r for r in refs if not r.endswith(":3")][:3]
+    assert "feat_n=3" in tB and not re.search(r":\d+:\d+:\d+:\d+:\d+:\d+", t1)
+    conv1 = [a for k, a in l1.ops if k == "conv"][3]
+    convB = [a for k, a in lB.ops if k == "conv"][3]
+    assert float(convB["bytes"]) < 3 * float(conv1["bytes"])      # the weights are read once per launch
