@@ -37,7 +37,9 @@ if __import__('os').environ.get("KSWEEP"):   # time vs K at fixed M, N: slope = 
     SHAPES = [("K=%d N=256 M=8192" % k, k, 256, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 64, 128, 256, 512, 1024, 2304, 4608, 8192)]
     SHAPES += [("K=%d N=1024 M=8192" % k, k, 1024, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 256, 1024, 4096)]
 if __import__('os').environ.get("BATCH4"):   # what would batching 4 frames buy?  each shape at 1x and at 4x the rows
-    base = [("res4_2a 1x1 1024-256", 1024, 256, 64, 128, 1, 1, 0, 1, 0), ("res4_2b 3x3 256-256", 256, 256, 64, 128, 3, 1, 1, 1, 0),
+    base = [("res2_2b 3x3 64-64 @256x512", 64, 64, 256, 512, 3, 1, 1, 1, 0), ("r18 s1 3x3 64-64 +res", 64, 64, 256, 512, 3, 1, 1, 1, 1),
+            ("res2_2a 1x1 256-64", 256, 64, 256, 512, 1, 1, 0, 1, 0),
+            ("res4_2a 1x1 1024-256", 1024, 256, 64, 128, 1, 1, 0, 1, 0), ("res4_2b 3x3 256-256", 256, 256, 64, 128, 3, 1, 1, 1, 0),
             ("res4_2c 1x1 256-1024+res", 256, 1024, 64, 128, 1, 1, 0, 1, 1), ("res3_2b 3x3 128-128", 128, 128, 128, 256, 3, 1, 1, 1, 0),
             ("res3_2c 1x1 128-512+res", 128, 512, 128, 256, 1, 1, 0, 1, 1), ("res5_2a 1x1 2048-512", 2048, 512, 64, 128, 1, 1, 0, 1, 0),
             ("r18 s3 3x3 256-256", 256, 256, 64, 128, 3, 1, 1, 1, 1), ("r18 res5 3x3 512-512 @32x64", 512, 512, 32, 64, 3, 1, 1, 1, 0),
