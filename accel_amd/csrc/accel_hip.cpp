@@ -1270,10 +1270,11 @@ struct TempModel {
     ~TempModel() { if (m) accel_model_destroy(m); }
 };
 
-std::string bref(const char* space, size_t off, int C, int Cs, int H, int W)
+std::string bref(const char* space, size_t off, int C, int Cs, int H, int W, int N = 1)
 {
-    char b[160];
-    snprintf(b, sizeof b, "%s:%zu:%d:%d:%d:%d", space, off, C, Cs, H, W);
+    char b[176];
+    if (N == 1) snprintf(b, sizeof b, "%s:%zu:%d:%d:%d:%d", space, off, C, Cs, H, W);
+    else snprintf(b, sizeof b, "%s:%zu:%d:%d:%d:%d:%d", space, off, C, Cs, H, W, N);
     return b;
 }
 
@@ -1303,7 +1304,7 @@ extern "C" int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H,
                             int act, float slope, int force_tile, float* y)
 {
     if (!ctx || !x || !w || !y) return fail(ACCEL_ERR_ARG, "accel_conv2d: NULL argument");
-    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_conv2d: N must be 1 (TEST.BATCH_IMAGES = 1 on this path)");
+    if (N < 1) return fail(ACCEL_ERR_ARG, "accel_conv2d: N must be >= 1");
     const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
     if (Ho <= 0 || Wo <= 0) return fail(ACCEL_ERR_ARG, "accel_conv2d: empty output");
     TempModel t;
@@ -1317,24 +1318,24 @@ extern "C" int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H,
             (rc = set1(t.m, "e_moving_mean", zero.data(), {K})) || (rc = set1(t.m, "e_moving_var", var.data(), {K}))) return rc;
     }
     const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4;
-    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)K * Ho * Wo * 4;
+    const size_t xin = (size_t)N * C * H * W * 4, yout = (size_t)N * K * Ho * Wo * 4;
     size_t off = 0;
-    const size_t o_x = off; off += al((size_t)H * W * Cp * 4);
-    const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
-    const size_t o_r = off; if (residual) off += al((size_t)Ho * Wo * Kp * 4);
+    const size_t o_x = off; off += al((size_t)N * H * W * Cp * 4);
+    const size_t o_y = off; off += al((size_t)N * Ho * Wo * Kp * 4);
+    const size_t o_r = off; if (residual) off += al((size_t)N * Ho * Wo * Kp * 4);
     std::stringstream s;
     s << "option graph=0 tune=0\narena bytes=" << off << "\n";
     s << "pbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
     if (residual) s << "pbuf name=r bytes=" << yout << "\n";
-    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
-    if (residual) s << "import_nchw src=" << bref("r", 0, K, K, Ho, Wo) << " dst=" << bref("A", o_r, K, Kp, Ho, Wo) << "\n";
-    s << "conv name=op in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, K, Kp, Ho, Wo)
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W, N) << " dst=" << bref("A", o_x, C, Cp, H, W, N) << "\n";
+    if (residual) s << "import_nchw src=" << bref("r", 0, K, K, Ho, Wo, N) << " dst=" << bref("A", o_r, K, Kp, Ho, Wo, N) << "\n";
+    s << "conv name=op in=" << bref("A", o_x, C, Cp, H, W, N) << " out=" << bref("A", o_y, K, Kp, Ho, Wo, N)
       << " w=w_weight" << (bias ? " bias=w_bias" : "") << (scale ? " bn=e eps=0 fixg=0" : "")
       << " act=" << act << " slope=" << slope << " k=" << kh << "," << kw << " s=" << sh << "," << sw
       << " p=" << ph << "," << pw << " d=" << dh << "," << dw << " cin=" << C << " cout=" << K
       << " tile=" << force_tile;
-    if (residual) s << " res=" << bref("A", o_r, K, Kp, Ho, Wo);
-    s << "\nexport_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    if (residual) s << " res=" << bref("A", o_r, K, Kp, Ho, Wo, N);
+    s << "\nexport_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo, N) << " dst=" << bref("y", 0, K, K, Ho, Wo, N) << "\n";
     accel_plan* p = nullptr;
     if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
     if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;
@@ -1347,22 +1348,22 @@ extern "C" int accel_deconv2d_4x4s2(accel_ctx* ctx, const float* x, int N, int C
                                     const float* w, const float* bias, int K, int act, float slope, float* y)
 {
     if (!ctx || !x || !w || !y) return fail(ACCEL_ERR_ARG, "accel_deconv2d_4x4s2: NULL argument");
-    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_deconv2d_4x4s2: N must be 1");
+    if (N < 1) return fail(ACCEL_ERR_ARG, "accel_deconv2d_4x4s2: N must be >= 1");
     TempModel t;
     int rc;
     if ((rc = accel_model_create(ctx, &t.m))) return rc;
     if ((rc = set1(t.m, "w_weight", w, {C, K, 4, 4}))) return rc;
     if (bias && (rc = set1(t.m, "w_bias", bias, {K}))) return rc;
     const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4, Ho = 2 * H, Wo = 2 * W;
-    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)K * Ho * Wo * 4;
-    const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Kp * 4);
+    const size_t xin = (size_t)N * C * H * W * 4, yout = (size_t)N * K * Ho * Wo * 4;
+    const size_t o_x = 0, o_y = al((size_t)N * H * W * Cp * 4), tot = o_y + al((size_t)N * Ho * Wo * Kp * 4);
     std::stringstream s;
     s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
-    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
-    s << "conv name=op mode=deconv2x in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, K, Kp, Ho, Wo)
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W, N) << " dst=" << bref("A", o_x, C, Cp, H, W, N) << "\n";
+    s << "conv name=op mode=deconv2x in=" << bref("A", o_x, C, Cp, H, W, N) << " out=" << bref("A", o_y, K, Kp, Ho, Wo, N)
       << " w=w_weight" << (bias ? " bias=w_bias" : "") << " act=" << act << " slope=" << slope
       << " cin=" << C << " cout=" << K << "\n";
-    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo, N) << " dst=" << bref("y", 0, K, K, Ho, Wo, N) << "\n";
     accel_plan* p = nullptr;
     if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
     if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;
@@ -1375,7 +1376,7 @@ extern "C" int accel_deform_conv2d(accel_ctx* ctx, const float* x, int N, int C,
                                    int sh, int sw, int ph, int pw, int dh, int dw, int dg, float* y)
 {
     if (!ctx || !x || !offset || !w || !y) return fail(ACCEL_ERR_ARG, "accel_deform_conv2d: NULL argument");
-    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_deform_conv2d: N must be 1");
+    if (N < 1) return fail(ACCEL_ERR_ARG, "accel_deform_conv2d: N must be >= 1");
     const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
     TempModel t;
     int rc;
@@ -1383,22 +1384,22 @@ extern "C" int accel_deform_conv2d(accel_ctx* ctx, const float* x, int N, int C,
     if ((rc = set1(t.m, "w_weight", w, {K, C, kh, kw}))) return rc;
     const int OC = 2 * kh * kw * dg;
     const int Cp = (C + 3) / 4 * 4, Kp = (K + 3) / 4 * 4, OCp = (OC + 3) / 4 * 4, CC = kh * kw * Cp;
-    const size_t xin = (size_t)C * H * W * 4, oin = (size_t)OC * Ho * Wo * 4, yout = (size_t)K * Ho * Wo * 4;
+    const size_t xin = (size_t)N * C * H * W * 4, oin = (size_t)N * OC * Ho * Wo * 4, yout = (size_t)N * K * Ho * Wo * 4;
     size_t off = 0;
-    const size_t o_x = off; off += al((size_t)H * W * Cp * 4);
-    const size_t o_o = off; off += al((size_t)Ho * Wo * OCp * 4);
-    const size_t o_c = off; off += al((size_t)Ho * Wo * CC * 4);
-    const size_t o_y = off; off += al((size_t)Ho * Wo * Kp * 4);
+    const size_t o_x = off; off += al((size_t)N * H * W * Cp * 4);
+    const size_t o_o = off; off += al((size_t)N * Ho * Wo * OCp * 4);
+    const size_t o_c = off; off += al((size_t)N * Ho * Wo * CC * 4);
+    const size_t o_y = off; off += al((size_t)N * Ho * Wo * Kp * 4);
     std::stringstream s;
     s << "option graph=0 tune=0\narena bytes=" << off << "\npbuf name=x bytes=" << xin << "\npbuf name=o bytes=" << oin << "\npbuf name=y bytes=" << yout << "\n";
-    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
-    s << "import_nchw src=" << bref("o", 0, OC, OC, Ho, Wo) << " dst=" << bref("A", o_o, OC, OCp, Ho, Wo) << "\n";
-    s << "dcn_cols in=" << bref("A", o_x, C, Cp, H, W) << " off=" << bref("A", o_o, OC, OCp, Ho, Wo)
-      << " out=" << bref("A", o_c, CC, CC, Ho, Wo) << " k=" << kh << "," << kw << " s=" << sh << "," << sw
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W, N) << " dst=" << bref("A", o_x, C, Cp, H, W, N) << "\n";
+    s << "import_nchw src=" << bref("o", 0, OC, OC, Ho, Wo, N) << " dst=" << bref("A", o_o, OC, OCp, Ho, Wo, N) << "\n";
+    s << "dcn_cols in=" << bref("A", o_x, C, Cp, H, W, N) << " off=" << bref("A", o_o, OC, OCp, Ho, Wo, N)
+      << " out=" << bref("A", o_c, CC, CC, Ho, Wo, N) << " k=" << kh << "," << kw << " s=" << sh << "," << sw
       << " p=" << ph << "," << pw << " d=" << dh << "," << dw << " dg=" << dg << "\n";
-    s << "conv name=op mode=cols wk=" << kh << "," << kw << " in=" << bref("A", o_c, CC, CC, Ho, Wo)
-      << " out=" << bref("A", o_y, K, Kp, Ho, Wo) << " w=w_weight act=0 k=1,1 cin=" << C << " cout=" << K << "\n";
-    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo) << " dst=" << bref("y", 0, K, K, Ho, Wo) << "\n";
+    s << "conv name=op mode=cols wk=" << kh << "," << kw << " in=" << bref("A", o_c, CC, CC, Ho, Wo, N)
+      << " out=" << bref("A", o_y, K, Kp, Ho, Wo, N) << " w=w_weight act=0 k=1,1 cin=" << C << " cout=" << K << "\n";
+    s << "export_nchw src=" << bref("A", o_y, K, Kp, Ho, Wo, N) << " dst=" << bref("y", 0, K, K, Ho, Wo, N) << "\n";
     accel_plan* p = nullptr;
     if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
     if ((rc = accel_model_write(t.m, "x", x, xin, 0)) || (rc = accel_model_write(t.m, "o", offset, oin, 0))) return rc;
@@ -1411,7 +1412,7 @@ extern "C" int accel_pool2d(accel_ctx* ctx, const float* x, int N, int C, int H,
                             const float* scale, const float* shift, int relu, float* y)
 {
     if (!ctx || !x || !y) return fail(ACCEL_ERR_ARG, "accel_pool2d: NULL argument");
-    if (N != 1) return fail(ACCEL_ERR_ARG, "accel_pool2d: N must be 1");
+    if (N < 1) return fail(ACCEL_ERR_ARG, "accel_pool2d: N must be >= 1");
     auto po = [&](int in, int k, int s, int p) {
         return full ? 1 + (in + 2 * p - k + s - 1) / s : 1 + (in + 2 * p - k) / s;
     };
@@ -1425,15 +1426,15 @@ extern "C" int accel_pool2d(accel_ctx* ctx, const float* x, int N, int C, int H,
             (rc = set1(t.m, "e_moving_mean", zero.data(), {C})) || (rc = set1(t.m, "e_moving_var", var.data(), {C}))) return rc;
     }
     const int Cp = (C + 3) / 4 * 4;
-    const size_t xin = (size_t)C * H * W * 4, yout = (size_t)C * Ho * Wo * 4;
-    const size_t o_x = 0, o_y = al((size_t)H * W * Cp * 4), tot = o_y + al((size_t)Ho * Wo * Cp * 4);
+    const size_t xin = (size_t)N * C * H * W * 4, yout = (size_t)N * C * Ho * Wo * 4;
+    const size_t o_x = 0, o_y = al((size_t)N * H * W * Cp * 4), tot = o_y + al((size_t)N * Ho * Wo * Cp * 4);
     std::stringstream s;
     s << "option graph=0 tune=0\narena bytes=" << tot << "\npbuf name=x bytes=" << xin << "\npbuf name=y bytes=" << yout << "\n";
-    s << "import_nchw src=" << bref("x", 0, C, C, H, W) << " dst=" << bref("A", o_x, C, Cp, H, W) << "\n";
-    s << "pool in=" << bref("A", o_x, C, Cp, H, W) << " out=" << bref("A", o_y, C, Cp, Ho, Wo)
+    s << "import_nchw src=" << bref("x", 0, C, C, H, W, N) << " dst=" << bref("A", o_x, C, Cp, H, W, N) << "\n";
+    s << "pool in=" << bref("A", o_x, C, Cp, H, W, N) << " out=" << bref("A", o_y, C, Cp, Ho, Wo, N)
       << " kind=" << (is_max ? "max" : "avg") << " k=" << kh << "," << kw << " s=" << sh << "," << sw
       << " p=" << ph << "," << pw << (scale ? " bn=e eps=0 fixg=0" : "") << " act=" << (relu ? 1 : 0) << "\n";
-    s << "export_nchw src=" << bref("A", o_y, C, Cp, Ho, Wo) << " dst=" << bref("y", 0, C, C, Ho, Wo) << "\n";
+    s << "export_nchw src=" << bref("A", o_y, C, Cp, Ho, Wo, N) << " dst=" << bref("y", 0, C, C, Ho, Wo, N) << "\n";
     accel_plan* p = nullptr;
     if ((rc = accel_model_add_plan(t.m, "op", s.str().c_str(), &p))) return rc;
     if ((rc = accel_model_write(t.m, "x", x, xin, 0))) return rc;

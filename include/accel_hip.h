@@ -106,7 +106,8 @@ int accel_cur_forward(accel_model* m, const float* img_cur, const float* img_pre
 
 /* ---- operator level (host fp32 NCHW in / out; used by the parity tests) --------
  * Each is the single MXNet operator named, run through the same kernels and the
- * same weight repacking as the plans. */
+ * same weight repacking as the plans.  N >= 1 for conv / deconv / deformable conv / pool (the
+ * convolution kernel runs the batch as one GEMM with M = N*Ho*Wo). */
 /* mx.symbol.Convolution (+ optional per-channel scale/shift, residual, activation:
  * the fused epilogue).  act: 0 none, 1 relu, 2 leaky(slope). */
 int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,

@@ -196,3 +196,30 @@ def test_argmax_ties_pick_first(ctx):
     got = ctx.argmax_c(x)
     np.testing.assert_array_equal(got, O.argmax_c(x))
     assert got[0, 0, 0] == 3 and got[0, 1, 1] == 5
+
+
+# ---- batched operators: images stacked pixel-major, M = N*Ho*Wo inside the conv kernel ---------------------
+@pytest.mark.parametrize("tile", [-1, 8, 10, 12, 31, 32, 33, 34, 9])
+def test_conv2d_batched(ctx, tile):
+    N, C, K, H, W = 3, 64, 136, 19, 27                   # ragged tiles; M = 3*10*14 rows straddle image boundaries
+    x, w, b = rnd(70, N, C, H, W), rnd(71, K, C, 3, 3, scale=0.05), rnd(72, K)
+    res = rnd(73, N, K, 10, 14)
+    ref = O.relu(O.conv2d(x, w, b, 2, 1, 1) + res)
+    close(ctx.conv2d(x, w, b, 2, 1, 1, residual=res, act=1, tile=tile), ref)
+
+
+def test_conv2d_batched_split_k_and_narrow(ctx):
+    x, w = rnd(74, 2, 512, 4, 8), rnd(75, 1024, 512, 3, 3, scale=0.03)      # low-res FlowNet shape: split-K path
+    close(ctx.conv2d(x, w, None, 1, 1, 1), O.conv2d(x, w, None, 1, 1, 1))
+    x2, w2, b2 = rnd(76, 3, 196, 12, 16), rnd(77, 2, 196, 3, 3, scale=0.05), rnd(78, 2)   # flow predictor: narrow-N kernel
+    close(ctx.conv2d(x2, w2, b2, 1, 1, 1), O.conv2d(x2, w2, b2, 1, 1, 1))
+
+
+def test_deconv_deform_pool_batched(ctx):
+    x, w = rnd(80, 2, 36, 6, 9), rnd(81, 36, 24, 4, 4, scale=0.1)
+    close(ctx.deconv2d_4x4s2(x, w), O.deconv2d(x, w, None, stride=2, pad=1))
+    xd, wd = rnd(82, 2, 16, 9, 11), rnd(83, 24, 16, 3, 3, scale=0.1)
+    off = rnd(84, 2, 18, 9, 11, scale=1.5)
+    close(ctx.deform_conv2d(xd, off, wd, 1, 2, 2, 1), O.deform_conv2d(xd, off, wd, 1, 2, 2, 1))
+    xp = rnd(85, 3, 12, 17, 23)
+    close(ctx.pool2d(xp, "max", 3, 2, 1, convention="full"), O.pool2d(xp, "max", 3, 2, 1, convention="full"))
