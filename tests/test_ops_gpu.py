@@ -223,3 +223,41 @@ def test_deconv_deform_pool_batched(ctx):
     close(ctx.deform_conv2d(xd, off, wd, 1, 2, 2, 1), O.deform_conv2d(xd, off, wd, 1, 2, 2, 1))
     xp = rnd(85, 3, 12, 17, 23)
     close(ctx.pool2d(xp, "max", 3, 2, 1, convention="full"), O.pool2d(xp, "max", 3, 2, 1, convention="full"))
+
+
+def _fuzz_cases(n, seed=20260929):
+    rng = np.random.RandomState(seed)
+    tiles = [-1, -1, 3, 8, 10, 11, 12, 31, 32, 33, 34, 4, 9]
+    out = []
+    for i in range(n):
+        k = int(rng.choice([1, 3, 3, 5, 7]))
+        d = int(rng.choice([1, 1, 2])) if k > 1 else 1
+        s = int(rng.choice([1, 1, 2]))
+        pad = int(rng.randint(0, (k // 2) * d + 1))
+        C = int(rng.choice([3, 6, 8, 20, 32, 64, 96, 130, 256]))
+        K = int(rng.choice([2, 5, 19, 32, 64, 72, 100, 136, 260]))
+        N = int(rng.choice([1, 1, 2, 3]))
+        H, W = int(rng.randint(d * (k - 1) + 1, 34)), int(rng.randint(d * (k - 1) + 1, 40))
+        out.append((i, N, C, K, H, W, k, s, pad, d, bool(rng.randint(2)), int(rng.randint(3)), bool(rng.randint(2)), int(rng.choice(tiles))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(48), ids=lambda c: "n%d_c%d_k%d_%dx%d_k%ds%dp%dd%d_t%d" % (c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[13]))
+def test_conv2d_fuzz(ctx, case):
+    """Seeded random geometries (channels off the 4/32 granules, every kernel/stride/dilation/padding mix the path
+    uses, batches, bias / residual / activation, forced and heuristic tiles) against the oracle."""
+    i, N, C, K, H, W, k, s, pad, d, use_bias, act, use_res, tile = case
+    x, w = rnd(1000 + i, N, C, H, W), rnd(2000 + i, K, C, k, k, scale=1.0 / np.sqrt(C * k * k))
+    b = rnd(3000 + i, K) if use_bias else None
+    ref = O.conv2d(x, w, b, s, pad, d)
+    res = rnd(4000 + i, *ref.shape) if use_res else None
+    if res is not None:
+        ref = ref + res
+    if act == 1:
+        ref = O.relu(ref)
+    elif act == 2:
+        ref = np.where(ref > 0, ref, 0.1 * ref)
+    if K <= 4 and tile in (10, 11, 12, 32, 33, 34):
+        tile = -1
+    got = ctx.conv2d(x, w, b, s, pad, d, residual=res, act=act, tile=tile)
+    close(got, ref)
