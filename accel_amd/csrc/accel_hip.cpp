@@ -703,47 +703,33 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     hipError_t e = hipSuccess;
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
-    // the byte movers run once per image of the batch (pointer offsets; a few us each), only the convolution is
-    // batched inside the kernel -- that is where the larger M pays
-    case OP_PREP_RGB:
-        for (int n = 0; n < op.b.N && e == hipSuccess; ++n)
-            e = launch_prep_rgb(op.a.ptr + (size_t)n * 3 * op.H * op.W, op.b.ptr + n * op.b.img(), op.H, op.W, op.p0, op.p1, st);
+    // batch: blockIdx.z = image for the byte movers (fixed stride between images), M = N*Ho*Wo inside the convolution
+    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, op.b.N, st); break;
+    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, op.c.N, st); break;
+    case OP_POOL: {
+        PoolParams q = op.pool;
+        q.N = op.a.N; q.x_img = op.a.img(); q.y_img = op.b.img();
+        e = launch_pool(q, st);
         break;
-    case OP_PREP_FLOW:
-        for (int n = 0; n < op.c.N && e == hipSuccess; ++n)
-            e = launch_prep_flow(op.a.ptr + (size_t)n * 3 * op.H * op.W, op.b.ptr + (size_t)n * 3 * op.H * op.W,
-                                 op.c.ptr + n * op.c.img(), op.H, op.W, st);
-        break;
-    case OP_POOL:
-        for (int n = 0; n < op.a.N && e == hipSuccess; ++n) {
-            PoolParams q = op.pool;
-            q.x += n * op.a.img(); q.y += n * op.b.img();
-            e = launch_pool(q, st);
-        }
-        break;
+    }
     case OP_WARP:
-        for (int n = 0; n < op.a.N && e == hipSuccess; ++n)
-            e = launch_flow_warp(op.a.ptr + n * op.a.img(), op.a.Cs, op.b.ptr + n * op.b.img(), op.b.Cs, op.c.ptr + n * op.c.img(), op.c.Cs,
-                                 op.a.C, op.a.H, op.a.W, op.d.set ? op.d.ptr + n * op.d.img() : nullptr, op.d.Cs, op.p0, st);
+        e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W,
+                             op.d.set ? op.d.ptr : nullptr, op.d.Cs, op.p0, op.a.N, st);
         break;
-    case OP_DCN_COLS:
-        for (int n = 0; n < op.a.N && e == hipSuccess; ++n) {
-            DcnColsParams q = op.dcn;
-            q.x += n * op.a.img(); q.off += n * op.b.img(); q.col += n * op.c.img();
-            e = launch_dcn_cols(q, st);
-        }
+    case OP_DCN_COLS: {
+        DcnColsParams q = op.dcn;
+        q.N = op.a.N;
+        e = launch_dcn_cols(q, st);
         break;
+    }
     case OP_SCORE_TAIL: {
         const int N = op.a.N;
         if (op.tail_z)     // low-resolution fusion is pixel-wise: one launch over all images
             e = launch_score_fuse_lowres(op.tail.left, op.tail.lCs, op.tail.right, op.tail.rCs, op.tail.cw, op.tail_z,
                                          op.tail_lowres.lCs, op.tail.ncls, N * op.tail.Hs * op.tail.Ws, st);
-        for (int n = 0; n < N && e == hipSuccess; ++n) {
+        if (e == hipSuccess) {
             ScoreTailParams q = op.tail_z ? op.tail_lowres : op.tail;
-            q.left += (size_t)n * q.Hs * q.Ws * q.lCs;
-            if (q.right) q.right += (size_t)n * q.Hs * q.Ws * q.rCs;
-            q.logits += (size_t)n * q.ncls * q.H * q.W;
-            q.labels += (size_t)n * q.H * q.W;
+            q.N = N;
             e = launch_score_tail(q, st);
         }
         break;

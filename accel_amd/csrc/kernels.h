@@ -48,11 +48,12 @@ size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns wo
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------
 // NCHW fp32 3xHxW image -> NHWC4 (c3 = 0); optional per-channel scale/shift (bn_data)
+// N images: src image stride 3*H*W, dst image stride 4*H*W
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W,
-                           const float* scale3, const float* shift3, hipStream_t st);
+                           const float* scale3, const float* shift3, int N, hipStream_t st);
 // FlowNet input: avgpool2x2(concat(cur/255, prev/255)) -> NHWC8 at H/2 x W/2 (c6,c7 = 0)
 hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W,
-                            hipStream_t st);
+                            int N, hipStream_t st);
 
 struct PoolParams {
     const float* x; float* y;
@@ -63,6 +64,8 @@ struct PoolParams {
     int is_max;
     const float* scale; const float* shift;   // optional BN epilogue
     int relu;
+    int N;                 // images (blockIdx.z); 0 = 1
+    size_t x_img, y_img;   // floats between consecutive images
 };
 hipError_t launch_pool(const PoolParams& p, hipStream_t st);
 
@@ -70,7 +73,7 @@ hipError_t launch_pool(const PoolParams& p, hipStream_t st);
 // optional second output out2 = relu(warped + bias[c]) (bias: C floats)
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs,
                             float* out, int oCs, int C, int H, int W,
-                            float* out2, int o2Cs, const float* bias, hipStream_t st);
+                            float* out2, int o2Cs, const float* bias, int N, hipStream_t st);
 
 struct DcnColsParams {
     const float* x; const float* off; float* col;
@@ -78,6 +81,7 @@ struct DcnColsParams {
     int H, W, Ho, Wo;
     int kh, kw, sh, sw, ph, pw, dh, dw;
     int dg;
+    int N;                 // images (blockIdx.z), each H*W*xCs / Ho*Wo*offCs / Ho*Wo*colCs floats apart; 0 = 1
 };
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st);
 
@@ -91,6 +95,7 @@ struct ScoreTailParams {
     int ncls, Hs, Ws, H, W;
     int softmax;                     // apply softmax over classes to the written scores (deeplab test symbol)
     int uniform_w;                   // wl is the same 32x32 filter for every class: 4-pixel-per-thread kernel
+    int N;                           // images (blockIdx.z), stacked in every buffer; 0 = 1
 };
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
 

@@ -11,11 +11,14 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------------------
 // image boundary: NCHW 3xHxW -> NHWC4
 // ---------------------------------------------------------------------------
+// (all byte movers below: blockIdx.z = image of the batch, images a fixed stride apart)
 __global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW,
                                 const float* scale, const float* shift)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= HW) return;
+    src += (size_t)blockIdx.z * 3 * HW;
+    dst += (size_t)blockIdx.z * 4 * HW;
     float r = src[i], g = src[HW + i], b = src[2 * HW + i];
     if (scale) {
         r = r * scale[0] + shift[0];
@@ -26,10 +29,10 @@ __global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict
 }
 
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W, const float* scale3,
-                           const float* shift3, hipStream_t st)
+                           const float* shift3, int N, hipStream_t st)
 {
     const int HW = H * W;
-    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, st, src, dst, HW, scale3, shift3);
+    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256), 1, N), dim3(256), 0, st, src, dst, HW, scale3, shift3);
     return hipGetLastError();
 }
 
@@ -42,6 +45,8 @@ __global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __r
     if (i >= Ho * Wo) return;
     const int oy = i / Wo, ox = i - oy * Wo;
     const size_t HW = (size_t)H * W;
+    cur += blockIdx.z * 3 * HW; prev += blockIdx.z * 3 * HW;
+    dst += (size_t)blockIdx.z * Ho * Wo * 8;
     float o[8];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -58,10 +63,10 @@ __global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __r
     d[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
-hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, hipStream_t st)
+hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, int N, hipStream_t st)
 {
     const int n = (H / 2) * (W / 2);
-    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, cur, prev, dst, H, W);
+    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256), 1, N), dim3(256), 0, st, cur, prev, dst, H, W);
     return hipGetLastError();
 }
 
@@ -84,7 +89,7 @@ __global__ void pool_kernel(PoolParams p)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iy = hs; iy < he; ++iy)
         for (int ix = ws; ix < we; ++ix) {
-            const float4 v = *reinterpret_cast<const float4*>(p.x + ((size_t)iy * p.W + ix) * p.xCs + c4 * 4);
+            const float4 v = *reinterpret_cast<const float4*>(p.x + blockIdx.z * p.x_img + ((size_t)iy * p.W + ix) * p.xCs + c4 * 4);
             if (p.is_max) {
                 acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
                 acc.z = v.z > acc.z ? v.z : acc.z; acc.w = v.w > acc.w ? v.w : acc.w;
@@ -106,13 +111,13 @@ __global__ void pool_kernel(PoolParams p)
         acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
         acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    *reinterpret_cast<float4*>(p.y + (size_t)pix * p.yCs + c4 * 4) = acc;
+    *reinterpret_cast<float4*>(p.y + blockIdx.z * p.y_img + (size_t)pix * p.yCs + c4 * 4) = acc;
 }
 
 hipError_t launch_pool(const PoolParams& p, hipStream_t st)
 {
     const long total = (long)p.Ho * p.Wo * p.C4;
-    hipLaunchKernelGGL(pool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(pool_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -130,6 +135,11 @@ __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)H * W * C4) return;
+    {
+        const size_t hw = (size_t)H * W * blockIdx.z;
+        feat += hw * fCs; flow += hw * flCs; out += hw * oCs;
+        if (out2) out2 += hw * o2Cs;
+    }
     const int c4 = (int)(idx % C4);
     const int pix = (int)(idx / C4);
     const int y = pix / W, x = pix - y * W;
@@ -168,11 +178,11 @@ __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
 }
 
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs, float* out, int oCs,
-                            int C, int H, int W, float* out2, int o2Cs, const float* bias, hipStream_t st)
+                            int C, int H, int W, float* out2, int o2Cs, const float* bias, int N, hipStream_t st)
 {
     const int C4 = C / 4;
     const long total = (long)H * W * C4;
-    hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, feat, fCs, flow, flCs,
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(total, 256), 1, N), dim3(256), 0, st, feat, fCs, flow, flCs,
                        out, oCs, C4, H, W, out2, o2Cs, bias);
     return hipGetLastError();
 }
@@ -194,7 +204,8 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
     const int i = tap / p.kw, j = tap - i * p.kw;
     const int cpg = p.C / p.dg;
     const int g = (c4 * 4) / cpg;
-    const float2 o = *reinterpret_cast<const float2*>(p.off + (size_t)pix * p.offCs + g * 2 * taps + 2 * tap);
+    const size_t zn = blockIdx.z;      // image of the batch
+    const float2 o = *reinterpret_cast<const float2*>(p.off + zn * p.Ho * p.Wo * p.offCs + (size_t)pix * p.offCs + g * 2 * taps + 2 * tap);
     const float oh = o.x, ow = o.y;
     const int h_in = oy * p.sh - p.ph, w_in = ox * p.sw - p.pw;
     const float h_im = (float)(h_in + i * p.dh) + oh;
@@ -212,7 +223,7 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
         // absolute coordinates, clamped only for memory safety (no effect on in-range samples)
         const int y0 = min(max(h_in + h_low, 0), p.H - 1), y1 = min(max(h_in + h_high, 0), p.H - 1);
         const int x0 = min(max(w_in + w_low, 0), p.W - 1), x1 = min(max(w_in + w_high, 0), p.W - 1);
-        const float* b = p.x + c4 * 4;
+        const float* b = p.x + zn * p.H * p.W * p.xCs + c4 * 4;
         const float4 v1 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x0) * p.xCs);
         const float4 v2 = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x1) * p.xCs);
         const float4 v3 = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x0) * p.xCs);
@@ -223,13 +234,13 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
         val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
         val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
     }
-    *reinterpret_cast<float4*>(p.col + (size_t)pix * p.colCs + (size_t)tap * p.C + c4 * 4) = val;
+    *reinterpret_cast<float4*>(p.col + zn * p.Ho * p.Wo * p.colCs + (size_t)pix * p.colCs + (size_t)tap * p.C + c4 * 4) = val;
 }
 
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)
 {
     const long total = (long)p.Ho * p.Wo * p.kh * p.kw * (p.C / 4);
-    hipLaunchKernelGGL(dcn_cols_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(dcn_cols_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -270,6 +281,13 @@ __device__ __forceinline__ void upsample_px(const float* __restrict__ s, int Cs,
 template <int NCLS>
 __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
 {
+    {   // image of the batch
+        const size_t zn = blockIdx.z;
+        p.left += zn * p.Hs * p.Ws * p.lCs;
+        if (p.right) p.right += zn * p.Hs * p.Ws * p.rCs;
+        p.logits += zn * p.ncls * p.H * p.W;
+        p.labels += zn * p.H * p.W;
+    }
     const int X = blockIdx.x * 64 + (threadIdx.x & 63);
     const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= p.W || Y >= p.H) return;
@@ -321,6 +339,13 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
 template <int NCLS>
 __global__ __launch_bounds__(256) void score_tail_uniform_kernel(ScoreTailParams p)
 {
+    {   // image of the batch
+        const size_t zn = blockIdx.z;
+        p.left += zn * p.Hs * p.Ws * p.lCs;
+        if (p.right) p.right += zn * p.Hs * p.Ws * p.rCs;
+        p.logits += zn * p.ncls * p.H * p.W;
+        p.labels += zn * p.H * p.W;
+    }
     const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= p.W || Y >= p.H) return;
@@ -383,14 +408,14 @@ __global__ __launch_bounds__(256) void score_tail_uniform_kernel(ScoreTailParams
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st)
 {
     if (p.uniform_w && !p.right && p.W % 4 == 0) {
-        dim3 g4(cdiv(p.W / 4, 64), cdiv(p.H, 4));
+        dim3 g4(cdiv(p.W / 4, 64), cdiv(p.H, 4), p.N > 0 ? p.N : 1);
         if (p.ncls == 19) hipLaunchKernelGGL(score_tail_uniform_kernel<19>, g4, dim3(256), 0, st, p);
         else if (p.ncls == 2) hipLaunchKernelGGL(score_tail_uniform_kernel<2>, g4, dim3(256), 0, st, p);
         else if (p.ncls == 21) hipLaunchKernelGGL(score_tail_uniform_kernel<21>, g4, dim3(256), 0, st, p);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    dim3 grid(cdiv(p.W, 64), cdiv(p.H, 4));
+    dim3 grid(cdiv(p.W, 64), cdiv(p.H, 4), p.N > 0 ? p.N : 1);
     if (p.ncls == 19) hipLaunchKernelGGL(score_tail_kernel<19>, grid, dim3(256), 0, st, p);
     else if (p.ncls == 2) hipLaunchKernelGGL(score_tail_kernel<2>, grid, dim3(256), 0, st, p);
     else if (p.ncls == 21) hipLaunchKernelGGL(score_tail_kernel<21>, grid, dim3(256), 0, st, p);
