@@ -170,6 +170,8 @@ def _run(a):
                 ln["gather"] = None
             gather_note = "disabled: %r" % (e,)
 
+    gather_failures = []
+
     def step():
         for i in range(a.interval):
             for ln in lanes:
@@ -182,7 +184,11 @@ def _run(a):
                     m.write_device("data_key", dev_frames[t - 1].data_ptr(), nbytes)
                     ln["cur"].run()
                 if ln["gather"] is not None:
-                    ln["gather"].submit()
+                    try:
+                        ln["gather"].submit()
+                    except Exception as e:      # a failing collective must not cost the whole measurement
+                        ln["gather"] = None
+                        gather_failures.append(repr(e))
 
     def sync():
         for ln in lanes:
@@ -226,7 +232,7 @@ def _run(a):
                                       "processed %d clips at a time (batched frames of independent clips)"
                                       % (a.version, a.version, H, W, a.interval, len(lanes) * B, a.interval - 1, B),
                           "frames_per_step_per_gpu": a.interval * len(lanes) * B, "clips_per_call": B, "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
-                          "gather": gather_note, "weights": "seeded random",
+                          "gather": gather_note + ("; DISABLED after failure: " + gather_failures[0] if gather_failures else ""), "weights": "seeded random",
                           "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
                                        "taken from the warped W_fc6*feat image of the key frame" if os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
                                        else "reference layer list one to one (ACCEL_FOLD_LINEAR=0)"), "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
