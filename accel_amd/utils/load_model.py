@@ -10,6 +10,9 @@ NDArray, legacy (MXNet <= 0.11, the reference's commit):
     uint32 ndim, uint32 dims[ndim], int32 dev_type, int32 dev_id, int32 type_flag, raw data
 NDArray, V1/V2 (MXNet >= 0.12): uint32 magic 0xF993FAC8 (V1) / 0xF993FAC9 (V2)
     [V2: int32 storage_type], uint32 ndim, int64 dims[ndim], context, type_flag, raw data
+NDArray, V3 (MXNet >= 1.6, numpy shape semantics): magic 0xF993FACA, layout of V2 with a signed ndim;
+    ndim 0 is a scalar WITH context / type_flag / one element, ndim -1 an unknown shape with nothing after it
+    (before V3 ndim 0 means "empty array" and ends the record).
 Names carry the `arg:` / `aux:` prefix (save_model.py:15-18).
 """
 import struct
@@ -17,7 +20,7 @@ import struct
 import numpy as np
 
 _LIST_MAGIC = 0x112
-_V1, _V2 = 0xF993FAC8, 0xF993FAC9
+_V1, _V2, _V3 = 0xF993FAC8, 0xF993FAC9, 0xF993FACA
 _DTYPES = {0: np.float32, 1: np.float64, 2: np.float16, 3: np.uint8, 4: np.int32, 5: np.int8, 6: np.int64}
 _FLAGS = {np.dtype(v): k for k, v in _DTYPES.items()}
 
@@ -27,6 +30,8 @@ class _Reader(object):
         self.b, self.o = buf, 0
 
     def take(self, fmt):
+        if self.o + struct.calcsize("<" + fmt) > len(self.b):
+            raise ValueError("truncated .params file")
         v = struct.unpack_from("<" + fmt, self.b, self.o)
         self.o += struct.calcsize("<" + fmt)
         return v if len(v) > 1 else v[0]
@@ -41,20 +46,28 @@ class _Reader(object):
 
 def _read_ndarray(r):
     first = r.take("I")
-    if first in (_V1, _V2):
-        if first == _V2:
+    scalar_ok = False
+    if first in (_V1, _V2, _V3):
+        if first != _V1:
             stype = r.take("i")
             if stype != 0:
                 raise NotImplementedError("sparse NDArray (storage type %d) in checkpoint" % stype)
-        ndim = r.take("I")
+        ndim = r.take("i") if first == _V3 else r.take("I")
+        scalar_ok = first == _V3
+        if ndim < 0:
+            return np.zeros((0,), np.float32)       # V3 "unknown shape": no payload
         shape = [r.take("q") for _ in range(ndim)]
     else:
         ndim = first
+        if ndim > 32:
+            raise ValueError("corrupt .params file: array of %d dimensions" % ndim)
         shape = [r.take("I") for _ in range(ndim)]
-    if ndim == 0:
-        return np.zeros((), np.float32)
-    r.take("ii")                       # context: dev_type, dev_id
+    if ndim == 0 and not scalar_ok:
+        return np.zeros((), np.float32)             # pre-V3: ndim 0 = empty array, record ends here
+    r.take("ii")                       # context: dev_type, dev_id (where it was saved from; irrelevant on load)
     flag = r.take("i")
+    if flag not in _DTYPES:
+        raise ValueError("corrupt or unsupported .params file: type flag %d" % flag)
     dt = np.dtype(_DTYPES[flag])
     n = int(np.prod(shape)) if shape else 1
     return np.frombuffer(r.raw(n * dt.itemsize), dtype=dt).reshape(shape).copy()

@@ -1,0 +1,194 @@
+"""BASELINE.json configs on hardware, one test per config ("configs not exercised"):
+
+  config 1  Accel-18, 512x1024 two-frame pair, key-frame interval 1 (both frames key, the reference's own
+            CPU-runnable case) and interval 2 (the warp / correction path) -- against the CPU oracle;
+  config 2/4  Accel-18 1024x2048, 8 clips per call (what bench.py times): the batched call against eight
+            batch-1 runs of the same clips;
+  config 3  Accel-101 1024x2048: the size-independent properties of test_golden_gpu.py for the other model
+            the BASELINE metric names;
+  config 4  the RCCL gather of per-frame logits, on one GPU (world size 1): gathered bytes == logits buffer;
+  config 5  Accel-50 with fp16-MFMA convolutions at 2048x4096, key-frame interval 10 schedule (3 frames of it):
+            finite logits, labels agree with the fp32 run of the same clip.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from accel_amd.utils import image, synth
+from oracle import graphs as G
+
+from parity_report import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frames(frames_bgr, cfg):
+    return [image.transform(f, cfg.network.PIXEL_MEANS).astype(np.float32) for f in frames_bgr]
+
+
+@pytest.mark.parametrize("interval", [1, 2])
+def test_config1_accel18_512x1024_pair(demo_cfg, interval):
+    """dff_deeplab demo on a 2-frame 512x1024 pair.  interval 1: `idx % 1 == 0` makes both frames key frames
+    (demo.py:235), the cur graph is not touched; interval 2: frame 1 goes through FlowNet, warp, the R18 branch and
+    the score fusion."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W = 512, 1024
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip("18", demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
+
+
+def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg):
+    """What bench.py times: one call = one frame of each of 8 independent clips at 1024x2048.  Image b of the batched
+    call must reproduce the batch-1 run of clip b over a key and a non-key frame (tile choices differ between the two
+    binds, so sums may differ in the last bits: 1e-4 of the logit range; labels identical outside the tie band)."""
+    from accel_amd import demo, mx
+    from accel_amd.core import tester
+    H, W, B, interval = 1024, 2048, 8, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    clips = [synth.make_clip(H, W, interval, seed=4100 + b) for b in range(B)]
+    per_clip = [demo.build_batches(c, demo_cfg) for c in clips]
+    try:
+        single = [[None] * interval for _ in range(B)]
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        for b in range(B):
+            for t in range(interval):
+                lg, lab = r.step(t, per_clip[b][t], interval)
+                # keep the sub-sampled logits and the full label map of every single run (8 x 160 MB otherwise)
+                single[b][t] = (lg.asnumpy()[0][:, ::2, ::2].copy(), np.uint8(lab.asnumpy()[0]))
+        tester.release_models()
+        rb = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W), batch=B)
+        for t in range(interval):
+            arrays = [mx.nd.array(np.concatenate([per_clip[b][t][i].asnumpy() for b in range(B)], axis=0)) for i in range(2)]
+            arrays.append(mx.nd.array(np.zeros((B, 2048, 1, 1), np.float32)))
+            logits, labels = rb.step(t, arrays, interval)
+            lg, lab = logits.asnumpy(), labels.asnumpy()
+            assert lg.shape == (B, 19, H, W) and lab.shape == (B, H, W)
+            for b in range(B):
+                ref, rlab = single[b][t]
+                tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+                err = float(np.abs(lg[b][:, ::2, ::2] - ref).max())
+                assert err <= tol, (t, b, err, tol)
+                assert float((np.uint8(lab[b]) != rlab).mean()) < 1e-4, (t, b)
+    finally:
+        tester.release_models()
+
+
+def test_config3_accel101_full_size_properties_1024x2048(demo_cfg):
+    """Accel-101 at the BASELINE size (the oracle takes minutes there): determinism, fused argmax == argmax of the
+    logits, a key frame inside a clip == the same frame first, zero flow + identical frames => warped feature ==
+    key feature, finite non-constant outputs."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W = 1024, 2048
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("101", H, W, demo_cfg)
+    for k in list(arg):                       # FlowNet predictors -> exactly zero flow
+        if k.startswith("Convolution") and arg[k].shape[0] == 2:
+            arg[k] = np.zeros_like(arg[k])
+    frames = synth.make_clip(H, W, 2)
+    frames = [frames[0], frames[0].copy()]
+    try:
+        data = demo.build_batches(frames, demo_cfg)
+        r = demo.ClipRunner("101", demo_cfg, arg, aux, (H, W))
+        lg_k, lab_k = r.step(0, data[0], 2)
+        a_logits, a_labels = lg_k.asnumpy().copy(), lab_k.asnumpy().copy()
+        feat_key = r.feat.asnumpy().copy()
+        lg_c, lab_c = r.step(1, data[1], 2)
+        c_logits, c_labels = lg_c.asnumpy().copy(), lab_c.asnumpy().copy()
+        np.testing.assert_allclose(r.feat.asnumpy(), feat_key, rtol=0, atol=1e-4 * float(np.abs(feat_key).max()))
+        np.testing.assert_array_equal(c_labels[0], np.argmax(c_logits[0], axis=0))
+        np.testing.assert_array_equal(a_labels[0], np.argmax(a_logits[0], axis=0))
+        lg_k2, _ = r.step(0, data[0], 2)
+        np.testing.assert_array_equal(lg_k2.asnumpy(), a_logits)
+        lg_c2, _ = r.step(1, data[1], 2)
+        np.testing.assert_array_equal(lg_c2.asnumpy(), c_logits)
+        lg_k3, _ = r.step(2, data[1], 1)
+        np.testing.assert_array_equal(lg_k3.asnumpy(), a_logits)
+        assert np.isfinite(c_logits).all() and len(np.unique(c_labels)) > 1
+        # Accel-101's non-key frame is a different function of the frame than the key graph (feature fusion
+        # 4096 -> 2048 on top of the warped feature): the two label maps must not be trivially equal
+        assert float((c_labels != a_labels).mean()) > 0
+    finally:
+        tester.release_models()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_config4_rccl_gather_on_one_gpu(demo_cfg):
+    """FrameGather over RCCL (backend "nccl") with a world of one rank: the gathered tensor of every frame must be
+    byte-identical to the model's logits / labels buffer, across more frames than staging slots."""
+    import torch
+    import torch.distributed as dist
+    from accel_amd import demo, dist as adist
+    from accel_amd.core import tester
+    H, W, interval = 128, 256, 3
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 4)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        data = demo.build_batches(frames, demo_cfg)
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        m = r.key_predictor._model
+        g_logits = adist.FrameGather(m, m.ctx, "logits", (1, 19, H, W), "f4", 0)
+        g_labels = adist.FrameGather(m, m.ctx, "labels", (1, H, W), "u1", 0)
+        for t in range(4):
+            lg, lab = r.step(t, data[t], interval)
+            s0, s1 = g_logits.submit(), g_labels.submit()
+            g_logits.drain()
+            g_labels.drain()
+            np.testing.assert_array_equal(g_logits.last(s0)[0].cpu().numpy(), lg.asnumpy())
+            np.testing.assert_array_equal(g_labels.last(s1)[0].cpu().numpy(), np.uint8(lab.asnumpy()))
+    finally:
+        tester.release_models()
+        dist.destroy_process_group()
+
+
+def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
+    """Accel-50, fp16-MFMA convolutions, 2048x4096 (config 5's frame size), the first three frames of a kf=10 group
+    (key, non-key, non-key: the chain through warp + correction branch).  Checked against the fp32 run of the same
+    clip on the same path: logits finite, mean error small against the logit range, labels agree on >= 99 %."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 2048, 4096, 10
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("50", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 3)
+    outs = {}
+    for dt in ("f32", "f16"):
+        monkeypatch.setenv("ACCEL_CONV_DTYPE", dt)
+        try:
+            res = demo.run_clip("50", demo_cfg, arg, aux, frames, interval)
+            outs[dt] = [(lg[0][:, ::4, ::4].copy(), lab.copy()) for lg, lab in res]    # keep 1/16 of the logits
+            del res
+        finally:
+            tester.release_models()
+    for t, ((a, la), (b, lb)) in enumerate(zip(outs["f32"], outs["f16"])):
+        assert np.isfinite(b).all(), "frame %d: non-finite fp16-mode logits" % t
+        scale = max(1.0, float(np.abs(a).max()))
+        assert float(np.abs(a - b).max()) <= 0.1 * scale, "frame %d" % t
+        assert float(np.abs(a - b).mean()) <= 1e-2 * scale, "frame %d" % t
+        assert float((la != lb).mean()) < 1e-2, "frame %d" % t
+        assert len(np.unique(la)) > 1

@@ -4,13 +4,16 @@ CPU oracle, same seeded weights and frames.
 
 Tolerance: |logit - oracle| <= 1e-3 * max(1, max|oracle logit|)  (BASELINE.json:
 "logits within 1e-3 fp32"); label maps must be identical wherever the oracle's
-top-2 margin exceeds twice that tolerance (ties inside the rounding band can
-legitimately flip), and the mismatch fraction overall must stay below 0.1 %."""
+top-2 margin exceeds twice the MEASURED logit error of the frame (inside that band
+a tie can legitimately flip), and the mismatch fraction overall must stay below
+0.1 %.  tests/parity_report.py logs the margin histogram of every frame."""
 import numpy as np
 import pytest
 
 from accel_amd.utils import image, synth
 from oracle import graphs as G
+
+from parity_report import check_against_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -20,14 +23,9 @@ def _oracle_frames(frames_bgr, cfg):
 
 
 def _check(outs, ref, tag):
-    for t, ((lg, lab), (rlg, rlab)) in enumerate(zip(outs, ref)):
-        tol = 1e-3 * max(1.0, float(np.abs(rlg).max()))
-        err = float(np.abs(lg - rlg).max())
-        assert err <= tol, "%s frame %d: logits err %g > %g" % (tag, t, err, tol)
-        srt = np.sort(rlg, axis=1)
-        safe = ((srt[:, -1] - srt[:, -2]) > 2 * tol)[0]
-        np.testing.assert_array_equal(lab[safe], rlab[0][safe])
-        assert float((lab != rlab[0]).mean()) < 1e-3
+    """logits within 1e-3 of the oracle; labels identical wherever the oracle's top-2 margin exceeds twice the MEASURED
+    logit error; margin histogram logged (tests/parity_report.py)"""
+    check_against_oracle(outs, ref, tag)
 
 
 @pytest.mark.parametrize("version", ["18", "34"])
