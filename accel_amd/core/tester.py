@@ -9,10 +9,14 @@ Contract kept from the reference:
   * predict(data_batch) -> [ {output_name: array} ] (one dict per device);
     inputs are copied into executor-owned buffers, outputs stay valid until the
     next forward; arrays are device handles whose .asnumpy() synchronises.
-  * a key predictor and a cur predictor built on the same context share the
-    propagated feature in HBM: feeding `feat` back as `feat_key`
-    (demo.py:241-243) costs nothing when it is the handle the previous predict
-    returned; a host array is uploaded instead.
+  * a key predictor and a cur predictor built on the same context with the SAME
+    parameters share one model, hence the propagated feature in HBM: feeding
+    `feat` back as `feat_key` (demo.py:241-243) costs nothing when it is the
+    handle the previous predict returned.  The handle carries the buffer's write
+    generation: if anything has overwritten the buffer since (another forward,
+    another predictor pair), the handle's host copy is uploaded when it has one
+    and the call fails loudly otherwise -- stale bytes are never read.  A host
+    array is always uploaded.
 Shapes are static per bind; a new (H, W) re-lowers and re-binds like
 MutableModule.forward does on a shape change (module.py:1026-1042).
 """
@@ -24,7 +28,7 @@ from .. import lower as _lower
 from .. import runtime
 from ..mx.ndarray import DeviceArray
 
-_MODELS = {}   # (device id, H, W) -> shared runtime.Model: the key and cur plans of one demo share buffers
+_MODELS = {}   # (device id, N, H, W, parameter token, owner) -> runtime.Model: the key and cur plans of one demo share buffers
 
 
 def _device_id(context):
@@ -32,29 +36,49 @@ def _device_id(context):
     return int(getattr(ctx, "device_id", 0) or 0)
 
 
-def shared_model(device_id, hw=None):
-    """One model per device and frame size: persistent buffers (`data`, `feat`, `logits`...) are sized
-    at the first bind and baked into captured graphs, so another resolution gets its own model."""
-    key = (device_id,) + tuple(hw or ())
+def params_token(*dicts):
+    """Content hash of parameter dicts (names, shapes, bytes).  Two predictors share a model -- and with it the
+    repacked weights in HBM -- only when their parameters are the same BYTES; another network or another checkpoint
+    gets its own model instead of overwriting same-named weights (fc6_weight, score_weight ... exist in every Accel
+    variant).  ~0.1 s for the 0.45 GB of Accel-18."""
+    import xxhash
+    h = xxhash.xxh3_64()
+    for d in dicts:
+        for k in sorted(d):
+            v = d[k]
+            a = np.ascontiguousarray(v.asnumpy() if hasattr(v, "asnumpy") else v)
+            h.update(("%s|%s|%s|" % (k, a.shape, a.dtype)).encode())
+            h.update(memoryview(a).cast("B"))
+    return h.hexdigest()
+
+
+def shared_model(device_id, hw=None, token="", owner=None):
+    """One model per device, frame size, parameter content and owner: persistent buffers (`data`, `feat`, `logits`...)
+    are sized at the first bind and baked into captured graphs, so another resolution gets its own model.  `owner`
+    scopes the sharing: a ClipRunner passes its own tag so that its key and cur predictor share buffers with each
+    other and with nobody else; predictors built without one (reference-style code) share per device."""
+    key = (device_id,) + tuple(hw or ()) + (token, owner)
     if key not in _MODELS:
         _MODELS[key] = runtime.Model(runtime.Context(device_id))
     return _MODELS[key]
 
 
-def release_models():
-    for m in _MODELS.values():
+def release_models(owner=None):
+    """Frees the models (weights, arenas, persistent buffers) bound so far -- all of them, or one owner's."""
+    for key in [k for k in _MODELS if owner is None or k[-1] == owner]:
+        m = _MODELS.pop(key)
         m.close()
         m.ctx.close()
-    _MODELS.clear()
 
 
 class Predictor(object):
     def __init__(self, symbol, data_names, label_names, context=None, max_data_shapes=None,
-                 provide_data=None, provide_label=None, arg_params=None, aux_params=None, model=None):
+                 provide_data=None, provide_label=None, arg_params=None, aux_params=None, model=None, owner=None):
         self._symbol = symbol
         self._data_names = list(data_names)
         self.output_names = symbol.list_outputs()
         self._explicit_model = model
+        self._owner = owner
         self._device_id = _device_id(context)
         self._model = model
         self._arg_params = arg_params or {}
@@ -100,23 +124,25 @@ class Predictor(object):
         shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}
         self._check_params(self._symbol, shapes)
         model = self._explicit_model
+        token = params_token(self._arg_params, self._aux_params)
         if model is None:
-            model = shared_model(self._device_id, (N, H, W))
-        loaded = getattr(model, "_loaded_from", set())
-        if id(self._arg_params) not in loaded:
+            model = shared_model(self._device_id, (N, H, W), token, self._owner)
+        if getattr(model, "_params_token", None) != token:
+            if getattr(model, "_params_token", None) is not None and model.plans:
+                raise runtime.AccelError("this model already holds plans bound to other parameters; bind another network "
+                                         "or checkpoint on its own runtime.Model")
             model.set_params(self._arg_params, self._aux_params)
-            loaded.add(id(self._arg_params))
-            model._loaded_from = loaded
+            model._params_token = token
         self._model = model
         text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
                                 conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
                                 fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
         if lw.derived:
             done = getattr(model, "_derived_from", {})
-            todo = {k: v for k, v in lw.derived.items() if done.get(k) != id(self._arg_params)}
+            todo = {k: v for k, v in lw.derived.items() if done.get(k) != token}
             for name, w in _lower.fold_params(todo, self._arg_params).items():
                 model.set_param(name, w)
-                done[name] = id(self._arg_params)
+                done[name] = token
             model._derived_from = done
         for name, d in lw.derived_bufs.items():      # rebuild plans of the derived persistent buffers (featG = fc6_weight * feat)
             if not self._is_key and ("init:" + name) not in model.plans:
@@ -138,26 +164,45 @@ class Predictor(object):
         self._model = m
         # Host->HBM copies are the dominant cost of the reference's per-frame loop (25 MB fp32 per image).  The key
         # graph does not read `data_key`, and on non-key frames `data_key` is the previous call's `data` array
-        # (demo.py:176-181 builds it that way): when it is the same object with the same content fingerprint the
-        # image is copied inside HBM instead of crossing PCIe again.
+        # (demo.py:176-181 builds it that way).  Arrays are immutable and carry a uid, so "the bytes of this input are
+        # already in that HBM buffer" is an identity check: the image is then copied inside HBM (or not at all)
+        # instead of crossing PCIe again.  An input announced with prefetch() is taken from its shadow buffer.
         res = m.__dict__.setdefault("_resident", {})
+        pre = m.__dict__.setdefault("_prefetched", {})
         if not self._is_key:
-            tag = _fingerprint(arrays["data_key"])
-            if res.get("data_key") != tag:
-                if res.get("data") == tag:
+            tag = _uid(arrays["data_key"])
+            if tag is None or res.get("data_key") != tag:
+                if tag is not None and res.get("data") == tag:
                     ptr, _ = m.buffer("data_key")
                     m.read_device("data", ptr, N * 3 * H * W * 4)
                 else:
                     m.write("data_key", _host(arrays["data_key"]))
                 res["data_key"] = tag
-        tag = _fingerprint(arrays["data"])
-        if res.get("data") != tag:
-            m.write("data", _host(arrays["data"]))
+        tag = _uid(arrays["data"])
+        if tag is None or res.get("data") != tag:
+            if tag is not None and pre.get("data") == tag:
+                m.commit("data")
+            else:
+                m.write("data", _host(arrays["data"]))
             res["data"] = tag
+        pre.pop("data", None)
         if not self._is_key:
             fk = arrays["feat_key"]
             ref = getattr(fk, "device_ref", None)
-            if not (ref and ref[0] is m and ref[1] == "feat"):
+            if ref and ref[0] is m and ref[1] == "feat" and ref[2] == m.generation("feat"):
+                pass                                   # the handle IS the current content of the shared buffer
+            elif ref and not getattr(fk, "has_host_copy", True):
+                if ref[1] == "feat" and ref[0] is not m and ref[2] == ref[0].generation("feat") and ref[0].ctx.device_id == m.ctx.device_id:
+                    # a handle of ANOTHER model on this GPU that is still current there: copy HBM to HBM
+                    ref[0].ctx.sync()
+                    src, n = ref[0].buffer("feat")
+                    m.write_device("feat", src, N * 2048 * (H // 16) * (W // 16) * 4)
+                else:
+                    raise runtime.AccelError(
+                        "feat_key is a device handle whose buffer has been overwritten since it was produced (outputs are "
+                        "valid until the next forward that writes them); call .asnumpy() on it before that forward to "
+                        "keep a copy, or give each predictor pair its own runtime.Model")
+            else:
                 self._upload_feat(_host(fk), N, H, W)
         plan.run()
         out = {}
@@ -177,9 +222,9 @@ class Predictor(object):
         def labels():
             # mx.ndarray.argmax returns float indices; the fused kernel wrote uint8 labels
             return DeviceArray(shape=(N, H, W), fetch=lambda: m.read("labels", (N, H, W), np.uint8).astype(np.float32),
-                               device_ref=(m, "labels"))
+                               device_ref=(m, "labels", m.generation("labels")))
         return DeviceArray(shape=(N, ncls, H, W), fetch=lambda: m.read("logits", (N, ncls, H, W)),
-                           device_ref=(m, "logits"), labels_of=labels)
+                           device_ref=(m, "logits", m.generation("logits")), labels_of=labels)
 
     def _feat_handle(self, N, H, W):
         m = self._model
@@ -188,7 +233,14 @@ class Predictor(object):
         def fetch():
             nhwc = m.read("feat", (N, h, w, 2048))
             return np.ascontiguousarray(nhwc.transpose(0, 3, 1, 2))
-        return DeviceArray(shape=(N, 2048, h, w), fetch=fetch, device_ref=(m, "feat"))
+        gen = m.generation("feat")
+
+        def fetch_checked():
+            if m.generation("feat") != gen:
+                raise runtime.AccelError("this feature handle is stale: its buffer has been written since (fetch it with "
+                                         ".asnumpy() before the next forward that propagates a feature)")
+            return fetch()
+        return DeviceArray(shape=(N, 2048, h, w), fetch=fetch_checked, device_ref=(m, "feat", gen))
 
     def _upload_feat(self, feat_nchw, N, H, W):
         f = np.asarray(feat_nchw, np.float32)
@@ -196,19 +248,25 @@ class Predictor(object):
             raise ValueError("feat_key shape %s does not match the bound graph" % (f.shape,))
         self._model.write("feat", np.ascontiguousarray(f.transpose(0, 2, 3, 1)))
 
+    def prefetch(self, data_array):
+        """Announce the NEXT call's `data` input: a page-locked array (mx.nd.array(.., ctx=mx.cpu_pinned())) starts
+        crossing PCIe on the copy stream now, beside the running forward; the next predict() that receives this very
+        array takes it from the shadow buffer.  Anything else is ignored (uploaded at predict time as usual)."""
+        pb = getattr(data_array, "pinned", None)
+        if pb is None or self._model is None:
+            return False
+        self._model.prefetch("data", pb)
+        self._model.__dict__.setdefault("_prefetched", {})["data"] = data_array.uid
+        return True
+
     def plan_for(self, H, W, N=1):
         plan, lw, _ = self._bind((H, W), N)
         return plan, lw
 
 
-def _fingerprint(a):
-    """(host address, shape, sampled content) of an input array: equal tags <=> the bytes already in HBM are still
-    valid.  The address identifies the host buffer (two mx.nd.array() handles of one numpy image share it, as in
-    demo.py:176-181); the sample (4096 strided elements) catches in-place edits and recycled addresses."""
-    h = a.asnumpy() if hasattr(a, "asnumpy") else np.asarray(a)
-    flat = h.reshape(-1)
-    step = max(1, flat.size // 4096)
-    return (h.ctypes.data, h.shape, str(h.dtype), float(np.asarray(flat[::step], np.float64).sum()), float(flat[-1]))
+def _uid(a):
+    """content identity of an input array: DeviceArrays are immutable, raw numpy inputs have none (always uploaded)"""
+    return getattr(a, "uid", None)
 
 
 def _host(a):

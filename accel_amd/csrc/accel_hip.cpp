@@ -6,6 +6,9 @@
 // liveness planner) or the name of a model-level persistent buffer.
 // Parameters are referenced by their MXNet names and repacked here.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -56,6 +59,7 @@ struct accel_ctx {
     int device;
     hipStream_t stream;     // compute stream (the one callers order against)
     hipStream_t stream1;    // side stream for the independent branch of two-stream plans
+    hipStream_t copy;       // host<->HBM prefetch stream (accel_model_prefetch)
 };
 
 struct HostParam {
@@ -81,7 +85,11 @@ struct accel_model {
     // plan that reads a stale derived buffer first runs the model's `init:<name>` plan (see accel_plan_run).
     std::map<std::string, std::string> derived_from;
     std::map<std::string, bool> derived_valid;
+    std::map<std::string, uint64_t> generation;     // write generation per persistent buffer (accel_model_buffer_generation)
+    struct Shadow { void* ptr = nullptr; size_t bytes = 0, filled = 0; hipEvent_t ready = nullptr, consumed = nullptr; bool was_consumed = false; };
+    std::map<std::string, Shadow> shadows;          // prefetch targets (accel_model_prefetch / accel_model_commit)
     void source_written(const std::string& src) {
+        ++generation[src];
         for (auto& kv : derived_from) if (kv.second == src) derived_valid[kv.first] = false;
     }
 };
@@ -530,6 +538,8 @@ static int finalize_conv(accel_plan* p, Op& op)
         c.ktab = static_cast<const int4*>(dt);
     }
     c.force_tile = (int)kv_int(kv, "tile", -1);
+    if (c.force_tile >= 0 && !conv_tile_valid(c.force_tile))
+        return fail(ACCEL_ERR_ARG, "conv %s: launch geometry id %d is not part of this build", op.name.c_str(), c.force_tile);
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;
@@ -784,39 +794,90 @@ struct TuneKey {
 };
 struct TuneVal { int tile, split_target, no_split; };
 static std::map<TuneKey, TuneVal> g_tune_cache;
+static std::map<TuneKey, TuneVal> g_tune_shipped;      // entries of the in-tree table (never written back to the user file)
 static bool g_tune_loaded = false;
 
-// Optional persistence (ACCEL_TUNE_CACHE=<file>): lets a profiled run skip the tuning launches.
-static void tune_cache_load()
+// Launch-geometry decisions are persisted so that they are REPRODUCIBLE: the summation order of a convolution (tile,
+// split-K) decides its last bits, and a decision taken by timing can differ from process to process.
+//   1. <directory of libaccel_hip.so>/tune/gfx950.tune  -- shipped with the sources, covers the BASELINE workloads;
+//   2. the user file: $ACCEL_TUNE_CACHE, else $XDG_CACHE_HOME/accel_amd/gfx950.tune, else ~/.cache/accel_amd/gfx950.tune
+//      -- shapes the shipped table lacks are timed ONCE, written there, and replayed by every later process.
+// A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
+// ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
+// (static heuristic for every shape that is in neither file).
+#define ACCEL_TUNE_VERSION "accel_hip-tune-3"
+
+static std::string lib_dir()
 {
-    if (g_tune_loaded) return;
-    g_tune_loaded = true;
-    const char* path = getenv("ACCEL_TUNE_CACHE");
-    if (!path) return;
-    FILE* f = fopen(path, "r");
+    Dl_info info;
+    if (!dladdr((const void*)&accel_last_error, &info) || !info.dli_fname) return ".";
+    std::string path(info.dli_fname);
+    const size_t slash = path.rfind('/');
+    return slash == std::string::npos ? "." : path.substr(0, slash);
+}
+
+static std::string user_tune_path()
+{
+    if (const char* e = getenv("ACCEL_TUNE_CACHE")) return e;
+    std::string dir;
+    if (const char* x = getenv("XDG_CACHE_HOME")) dir = x;
+    else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache";
+    else return "";
+    return dir + "/accel_amd/gfx950.tune";
+}
+
+static void tune_file_load(const std::string& path, std::map<TuneKey, TuneVal>& into)
+{
+    if (path.empty()) return;
+    FILE* f = fopen(path.c_str(), "r");
     if (!f) return;
+    char tag[64] = {0};
+    if (fscanf(f, "# %63s", tag) != 1 || strcmp(tag, ACCEL_TUNE_VERSION)) { fclose(f); return; }
     TuneKey k; TuneVal v;
     for (;;) {
         int n = 0;
         for (int i = 0; i < 16; ++i) n += fscanf(f, "%d", &k.v[i]);
         n += fscanf(f, "%d %d %d", &v.tile, &v.split_target, &v.no_split);
         if (n != 19) break;
-        g_tune_cache[k] = v;
+        into[k] = v;
     }
     fclose(f);
 }
 
+static void tune_cache_load()
+{
+    if (g_tune_loaded) return;
+    g_tune_loaded = true;
+    tune_file_load(user_tune_path(), g_tune_cache);
+    const char* sh = getenv("ACCEL_TUNE_SHIPPED");
+    if (!(sh && sh[0] == '0')) {
+        tune_file_load(lib_dir() + "/tune/gfx950.tune", g_tune_shipped);
+        for (const auto& kv : g_tune_shipped) g_tune_cache[kv.first] = kv.second;     // the shipped decision wins
+    }
+}
+
 static void tune_cache_save()
 {
-    const char* path = getenv("ACCEL_TUNE_CACHE");
-    if (!path) return;
-    FILE* f = fopen(path, "w");
+    const std::string path = user_tune_path();
+    if (path.empty()) return;
+    const bool explicit_file = getenv("ACCEL_TUNE_CACHE") != nullptr;     // an explicit file receives every entry
+    if (!explicit_file) {
+        const size_t slash = path.rfind('/');
+        std::string dir = path.substr(0, slash), up = dir.substr(0, dir.rfind('/'));
+        mkdir(up.c_str(), 0755);
+        mkdir(dir.c_str(), 0755);
+    }
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "w");
     if (!f) return;
+    fprintf(f, "# %s\n", ACCEL_TUNE_VERSION);
     for (const auto& kv : g_tune_cache) {
+        if (!explicit_file && g_tune_shipped.count(kv.first)) continue;
         for (int i = 0; i < 16; ++i) fprintf(f, "%d ", kv.first.v[i]);
         fprintf(f, "%d %d %d\n", kv.second.tile, kv.second.split_target, kv.second.no_split);
     }
     fclose(f);
+    rename(tmp.c_str(), path.c_str());      // atomic: concurrent ranks never read a half-written table
 }
 
 static size_t conv_apply(ConvParams& c, int tile, int split_target, int no_split)
@@ -939,6 +1000,7 @@ extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
     c->device = device_id;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream1, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(ACCEL_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     *out = c;
     return 0;
@@ -949,8 +1011,10 @@ extern "C" int accel_ctx_destroy(accel_ctx* ctx)
     if (!ctx) return 0;
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream1);
+    hipStreamSynchronize(ctx->copy);
     hipStreamDestroy(ctx->stream);
     hipStreamDestroy(ctx->stream1);
+    hipStreamDestroy(ctx->copy);
     delete ctx;
     return 0;
 }
@@ -991,6 +1055,7 @@ extern "C" int accel_model_destroy(accel_model* m)
     hipStreamSynchronize(m->ctx->stream);
     for (accel_plan* p : m->plans) plan_free(p);
     for (auto& kv : m->pbufs) hipFree(kv.second.ptr);
+    for (auto& kv : m->shadows) { if (kv.second.ready) hipEventDestroy(kv.second.ready); if (kv.second.consumed) hipEventDestroy(kv.second.consumed); hipFree(kv.second.ptr); }
     delete m;
     return 0;
 }
@@ -1058,22 +1123,51 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
     }
     HIP_TRY(hipDeviceSynchronize());
-    if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
     const char* g = getenv("ACCEL_HIP_GRAPH");
     const bool use_graph = p->allow_graph && !(g && g[0] == '0');
+    // Autotuning and the warm-up run below EXECUTE ops of this plan on the real buffers.  Persistent buffers the plan
+    // writes are live model state (a non-key plan warps `feat` / `featG` in place; a lazily bound plan is finalized
+    // between two frames of a clip), so they are saved first and put back afterwards: finalizing a plan never changes
+    // what the next forward sees.  Derived-buffer validity is untouched for the same reason.
+    struct Saved { std::string name; void* copy; size_t bytes; };
+    std::vector<Saved> saved;
+    auto restore = [&]() -> int {
+        hipStream_t st = p->m->ctx->stream;
+        int rc = 0;
+        for (Saved& sv : saved) {
+            if (!rc && hipMemcpyAsync(p->m->pbufs[sv.name].ptr, sv.copy, sv.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                rc = fail(ACCEL_ERR_HIP, "restoring persistent buffer %s after plan finalisation failed", sv.name.c_str());
+        }
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(ACCEL_ERR_HIP, "sync after plan finalisation failed");
+        for (Saved& sv : saved) hipFree(sv.copy);
+        saved.clear();
+        return rc;
+    };
+    if (p->allow_tune || use_graph) {
+        for (const std::string& name : p->pbuf_writes) {
+            DevBuf& b = p->m->pbufs[name];
+            Saved sv{name, nullptr, b.bytes};
+            if (hipMalloc(&sv.copy, b.bytes) != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "hipMalloc(%zu) for the snapshot of %s failed", b.bytes, name.c_str()); }
+            saved.push_back(sv);
+            if (hipMemcpyAsync(sv.copy, b.ptr, b.bytes, hipMemcpyDeviceToDevice, p->m->ctx->stream) != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "snapshot of %s failed", name.c_str()); }
+        }
+    }
+    if (p->allow_tune) { int trc = autotune_plan(p); if (trc) { restore(); return trc; } HIP_TRY(hipDeviceSynchronize()); }
     if (use_graph) {
         hipStream_t st = p->m->ctx->stream;
         // one eager warm-up run: lazy module loading / function attributes must not happen under capture
         int rc = run_eager(p);
-        if (rc) return rc;
+        if (rc) { restore(); return rc; }
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         rc = run_eager(p);
         hipError_t e = hipStreamEndCapture(st, &p->graph);
-        if (rc) return rc;
-        if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        if (rc) { restore(); return rc; }
+        if (e != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
         HIP_TRY(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
     }
+    int rrc = restore();
+    if (rrc) return rrc;
     p->finalized = true;
     return 0;
 }
@@ -1186,6 +1280,76 @@ extern "C" int accel_model_buffer(accel_model* m, const char* buf, void** dev_pt
     if (dev_ptr) *dev_ptr = it->second.ptr;
     if (bytes) *bytes = it->second.bytes;
     if (dev_ptr) m->source_written(buf);   // the caller may write through the raw pointer: derived buffers become stale
+    return 0;
+}
+
+extern "C" int accel_model_buffer_generation(accel_model* m, const char* buf, uint64_t* generation)
+{
+    if (!m || !buf || !generation) return fail(ACCEL_ERR_ARG, "accel_model_buffer_generation: NULL argument");
+    if (!m->pbufs.count(buf)) return fail(ACCEL_ERR_ARG, "accel_model_buffer_generation: unknown buffer '%s'", buf);
+    auto it = m->generation.find(buf);
+    *generation = it == m->generation.end() ? 0 : it->second;
+    return 0;
+}
+
+extern "C" int accel_host_alloc(size_t bytes, void** out)
+{
+    if (!out || !bytes) return fail(ACCEL_ERR_ARG, "accel_host_alloc: bad argument");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+extern "C" int accel_host_free(void* p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return 0;
+}
+
+extern "C" int accel_model_prefetch(accel_model* m, const char* buf, const void* pinned_src, size_t bytes)
+{
+    if (!m || !buf || !pinned_src) return fail(ACCEL_ERR_ARG, "accel_model_prefetch: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_prefetch: unknown buffer '%s'", buf);
+    if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_prefetch: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    accel_model::Shadow& sh = m->shadows[buf];
+    if (!sh.ptr) {
+        HIP_TRY(hipMalloc(&sh.ptr, it->second.bytes));
+        sh.bytes = it->second.bytes;
+        HIP_TRY(hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sh.consumed, hipEventDisableTiming));
+    } else if (sh.was_consumed) {
+        // the previous commit copied OUT of the shadow on the compute stream (event recorded right behind that copy,
+        // ahead of the plan that followed): do not overwrite under it -- and wait for nothing else on that stream
+        HIP_TRY(hipStreamWaitEvent(m->ctx->copy, sh.consumed, 0));
+    }
+    HIP_TRY(hipMemcpyAsync(sh.ptr, pinned_src, bytes, hipMemcpyHostToDevice, m->ctx->copy));
+    HIP_TRY(hipEventRecord(sh.ready, m->ctx->copy));
+    sh.filled = bytes;
+    return 0;
+}
+
+extern "C" int accel_model_commit(accel_model* m, const char* buf)
+{
+    if (!m || !buf) return fail(ACCEL_ERR_ARG, "accel_model_commit: NULL argument");
+    auto sh = m->shadows.find(buf);
+    if (sh == m->shadows.end() || !sh->second.filled) return fail(ACCEL_ERR_ARG, "accel_model_commit: nothing was prefetched for '%s'", buf);
+    HIP_TRY(hipStreamWaitEvent(m->ctx->stream, sh->second.ready, 0));
+    HIP_TRY(hipMemcpyAsync(m->pbufs[buf].ptr, sh->second.ptr, sh->second.filled, hipMemcpyDeviceToDevice, m->ctx->stream));
+    HIP_TRY(hipEventRecord(sh->second.consumed, m->ctx->stream));
+    sh->second.was_consumed = true;
+    sh->second.filled = 0;
+    m->source_written(buf);
+    return 0;
+}
+
+extern "C" int accel_model_read_async(accel_model* m, const char* buf, void* pinned_dst, size_t bytes)
+{
+    if (!m || !buf || !pinned_dst) return fail(ACCEL_ERR_ARG, "accel_model_read_async: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_read_async: unknown buffer '%s'", buf);
+    if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_read_async: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
+    HIP_TRY(hipMemcpyAsync(pinned_dst, it->second.ptr, bytes, hipMemcpyDeviceToHost, m->ctx->stream));
     return 0;
 }
 
@@ -1521,4 +1685,160 @@ extern "C" int accel_flow_input(accel_ctx* ctx, const float* cur, const float* p
     if ((rc = accel_model_write(t.m, "data", cur, ib, 0)) || (rc = accel_model_write(t.m, "data_key", prev, ib, 0))) return rc;
     if ((rc = accel_plan_finalize(p)) || (rc = accel_plan_run(p))) return rc;
     return accel_model_read(t.m, "y", out, ob, 0);
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU gather over RCCL (resolved at run time: a process that never creates a communicator needs no librccl,
+// and a process that already carries an RCCL -- torch.distributed's -- shares that copy instead of loading a second)
+// ---------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[128]; };
+typedef void* RcclComm;
+struct RcclApi {
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+RcclApi& rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (const char* e = getenv("ACCEL_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return api; }
+    auto sym = [&](const char* n) { void* f = dlsym(h, n); if (!f && api.why.empty()) api.why = std::string("librccl lacks ") + n; return f; };
+    api.GetUniqueId = reinterpret_cast<int (*)(RcclId*)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<int (*)(RcclComm*, int, RcclId, int)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<int (*)(RcclComm)>(sym("ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<int (*)()>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<int (*)()>(sym("ncclGroupEnd"));
+    api.Send = reinterpret_cast<int (*)(const void*, size_t, int, int, RcclComm, hipStream_t)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<int (*)(void*, size_t, int, int, RcclComm, hipStream_t)>(sym("ncclRecv"));
+    api.GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+    api.ok = api.why.empty();
+    return api;
+}
+}  // namespace
+
+struct accel_comm {
+    accel_ctx* ctx;
+    RcclComm comm = nullptr;
+    int rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;             // communication stream
+    void* stage[2] = {nullptr, nullptr};      // staging slots: the sender's copy of what is in flight
+    size_t stage_bytes[2] = {0, 0};
+    hipEvent_t staged[2] = {nullptr, nullptr};   // compute stream: slot filled
+    hipEvent_t sent[2] = {nullptr, nullptr};     // communication stream: transfer out of the slot finished
+    bool used[2] = {false, false};
+    unsigned long n = 0;
+};
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        int r__ = (expr);                                                                                \
+        if (r__ != 0) return fail(ACCEL_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r__) : "?"); \
+    } while (0)
+
+extern "C" int accel_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(ACCEL_ERR_ARG, "accel_comm_unique_id: NULL argument");
+    if (!rccl().ok) return fail(ACCEL_ERR_COMM, "%s", rccl().why.c_str());
+    RcclId id;
+    RCCL_TRY(rccl().GetUniqueId(&id));
+    memcpy(id128, id.internal, 128);
+    return 0;
+}
+
+extern "C" int accel_comm_create(accel_ctx* ctx, int rank, int nranks, const void* id128, accel_comm** out)
+{
+    if (!ctx || !id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(ACCEL_ERR_ARG, "accel_comm_create: bad argument");
+    if (!rccl().ok) return fail(ACCEL_ERR_COMM, "%s", rccl().why.c_str());
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<accel_comm> c(new accel_comm());
+    c->ctx = ctx; c->rank = rank; c->nranks = nranks;
+    RcclId id;
+    memcpy(id.internal, id128, 128);
+    RCCL_TRY(rccl().CommInitRank(&c->comm, nranks, id, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipEventCreateWithFlags(&c->staged[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->sent[s], hipEventDisableTiming));
+    }
+    *out = c.release();
+    return 0;
+}
+
+extern "C" int accel_comm_sync(accel_comm* c)
+{
+    if (!c) return fail(ACCEL_ERR_ARG, "accel_comm_sync: NULL communicator");
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));      // staging copies
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int accel_comm_destroy(accel_comm* c)
+{
+    if (!c) return 0;
+    hipStreamSynchronize(c->ctx->stream);
+    hipStreamSynchronize(c->stream);
+    if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
+    for (int s = 0; s < 2; ++s) {
+        if (c->stage[s]) hipFree(c->stage[s]);
+        if (c->staged[s]) hipEventDestroy(c->staged[s]);
+        if (c->sent[s]) hipEventDestroy(c->sent[s]);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* recvbuf_or_null, size_t bytes, int root)
+{
+    if (!c || !sendbuf || !bytes) return fail(ACCEL_ERR_ARG, "accel_gather_logits: bad argument");
+    if (root < 0 || root >= c->nranks) return fail(ACCEL_ERR_ARG, "accel_gather_logits: root %d out of range", root);
+    if (c->rank == root && !recvbuf_or_null) return fail(ACCEL_ERR_ARG, "accel_gather_logits: the root needs a receive buffer");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    const int s = (int)(c->n & 1);
+    hipStream_t compute = c->ctx->stream;
+    if (c->stage_bytes[s] < bytes) {
+        if (c->stage[s]) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->stage[s])); c->stage[s] = nullptr; }
+        HIP_TRY(hipMalloc(&c->stage[s], bytes));
+        c->stage_bytes[s] = bytes;
+    }
+    // (1) compute stream: wait until the transfer issued from this slot two calls ago has left it, then refill it
+    if (c->used[s]) HIP_TRY(hipStreamWaitEvent(compute, c->sent[s], 0));
+    HIP_TRY(hipMemcpyAsync(c->stage[s], sendbuf, bytes, hipMemcpyDeviceToDevice, compute));
+    HIP_TRY(hipEventRecord(c->staged[s], compute));
+    // (2) communication stream: point-to-point to the root, every peer over its own link; the root copies its own block
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[s], 0));
+    char* recv = static_cast<char*>(recvbuf_or_null);
+    if (c->rank == root) {
+        HIP_TRY(hipMemcpyAsync(recv + (size_t)root * bytes, c->stage[s], bytes, hipMemcpyDeviceToDevice, c->stream));
+        if (c->nranks > 1) {
+            RCCL_TRY(rccl().GroupStart());
+            for (int r = 0; r < c->nranks; ++r)
+                if (r != root) RCCL_TRY(rccl().Recv(recv + (size_t)r * bytes, bytes, /*ncclUint8*/ 1, r, c->comm, c->stream));
+            RCCL_TRY(rccl().GroupEnd());
+        }
+    } else {
+        RCCL_TRY(rccl().GroupStart());
+        RCCL_TRY(rccl().Send(c->stage[s], bytes, /*ncclUint8*/ 1, root, c->comm, c->stream));
+        RCCL_TRY(rccl().GroupEnd());
+    }
+    HIP_TRY(hipEventRecord(c->sent[s], c->stream));
+    c->used[s] = true;
+    ++c->n;
+    return 0;
 }

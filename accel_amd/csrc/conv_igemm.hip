@@ -925,6 +925,15 @@ int conv_pick_tile(const ConvParams& p)
 
 int conv_tile_bk(int tile) { return tile == 13 ? 64 : tile == 15 ? 16 : 32; }
 
+// launch-geometry ids this build carries (all of them compute the same contraction)
+bool conv_tile_valid(int tile)
+{
+#ifdef ACCEL_CONV_DIAG
+    if (tile >= 20 && tile <= 30) return true;
+#endif
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35);
+}
+
 static void tile_dims(int tile, int& bm, int& bn)
 {
     static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 256, 128, 128, 64, 128, 64};
@@ -1008,6 +1017,9 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 33: return launch_cfg<64, 128, 2, 4, 32, 3>(p, st);
         case 34: return launch_cfg<128, 64, 4, 2, 32, 3>(p, st);
         case 35: return launch_cfg<128, 32, 4, 1, 32, 3>(p, st);
+#ifdef ACCEL_CONV_DIAG
+        // timing-only ablation variants (they skip loads / stores / barriers and compute WRONG results): compiled into
+        // the diagnostics build alone (`make -C accel_amd/csrc diag`, scripts/microbench), never into libaccel_hip.so
         case 20: return launch_cfg<128, 128, 2, 2, 32, 0, 1>(p, st);   // ablation: no loads
         case 21: return launch_cfg<128, 128, 2, 2, 32, 0, 3>(p, st);   // ablation: no loads, no barrier
         case 22: return launch_cfg<128, 128, 2, 2, 32, 0, 2>(p, st);   // ablation: no barrier (racy, timing only)
@@ -1018,6 +1030,8 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         case 27: return launch_cfg<64, 64, 2, 2, 32, 0, 8>(p, st);
         case 28: return launch_cfg<64, 64, 2, 2, 32, 0, 1>(p, st);
         case 29: return launch_cfg<128, 128, 2, 2, 32, 0, 16>(p, st);  // setprio experiment
-        default: return launch_cfg<64, 64, 2, 2, 32, 0, 16>(p, st);    // 30
+        case 30: return launch_cfg<64, 64, 2, 2, 32, 0, 16>(p, st);
+#endif
+        default: return hipErrorInvalidValue;
     }
 }

@@ -44,6 +44,7 @@ struct ConvParams {
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
 int conv_pick_tile(const ConvParams& p);
 int conv_tile_bk(int tile);
+bool conv_tile_valid(int tile);
 size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns workspace bytes
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------

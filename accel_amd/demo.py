@@ -50,6 +50,14 @@ def select_frames(image_names, num_ex, interv, avg_acc, snip_len=30, lb_pos=19):
     return out
 
 
+def label_key(path):
+    """(city, sequence, frame) of a Cityscapes file name `<city>_<seq>_<frame>_<suffix>.png` -- the city is part of the
+    key: lindau_0000NN_000019 and munster_0000NN_000019 both exist in val for NN = 0..58 (the reference walks the label
+    list in order with lb_idx instead, demo.py:140-150,262-266)."""
+    c = os.path.basename(path).split('_')
+    return tuple(c[:3]) if len(c) > 3 else None
+
+
 def get_symbols(version, cfg):
     from . import symbols
     name = "accel_" + str(version)
@@ -57,20 +65,24 @@ def get_symbols(version, cfg):
     return inst, inst.get_key_test_symbol(cfg), inst.get_cur_test_symbol(cfg)
 
 
-def build_batches(frames_bgr, cfg):
-    """demo.py:165-190: list of [data, data_key, feat_key] arrays per frame."""
+def build_batches(frames_bgr, cfg, pinned=False):
+    """demo.py:165-190: list of [data, data_key, feat_key] arrays per frame.
+
+    One array per frame serves as this frame's `data` and as the next frame's `data_key` (the reference builds two
+    NDArrays from the same image, demo.py:176-181): arrays are immutable, so the Predictor recognises the object it
+    uploaded one call earlier and copies the image inside HBM instead of sending it over PCIe twice.
+    pinned=True places the images in page-locked memory (mx.cpu_pinned()), the source of overlapped uploads."""
     data, prev = [], None
+    ctx = mx.cpu_pinned() if pinned else None
+    zero_feat = mx.nd.array(np.zeros((1, cfg.network.DFF_FEAT_DIM, 1, 1)))
     for im in frames_bgr:
         target_size, max_size = cfg.SCALES[0][0], cfg.SCALES[0][1]
         im, _ = resize(im, target_size, max_size, stride=cfg.network.IMAGE_STRIDE)
-        # one fp32 host image per frame, shared by this frame's `data` handle and the next frame's `data_key` handle:
-        # the Predictor recognises the shared buffer and copies it inside HBM instead of uploading it twice
-        im_tensor = np.ascontiguousarray(transform(im, cfg.network.PIXEL_MEANS), dtype=np.float32)
+        cur = mx.nd.array(transform(im, cfg.network.PIXEL_MEANS), ctx=ctx)
         if prev is None:
-            prev = im_tensor
-        data.append([mx.nd.array(im_tensor), mx.nd.array(prev),
-                     mx.nd.array(np.zeros((1, cfg.network.DFF_FEAT_DIM, 1, 1)))])
-        prev = im_tensor
+            prev = cur
+        data.append([cur, prev, zero_feat])
+        prev = cur
     return data
 
 
@@ -79,8 +91,16 @@ class ClipRunner(object):
 
     data_names = ['data', 'data_key', 'feat_key']
 
-    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None, model=None, batch=1):
+    _tags = 0
+
+    def __init__(self, version, cfg, arg_params, aux_params, frame_hw, context=None, model=None, batch=1, share_models=False):
+        """`model`: bind both predictors on this runtime.Model (the bench does).  Otherwise the runner's two predictors
+        share models with each other only -- two runners interleaving clips of the same size do not see each other's
+        propagated feature -- unless share_models=True (one model per device, size and parameter content, as for
+        predictors built directly)."""
         self.version = str(version)
+        ClipRunner._tags += 1
+        self.owner = None if (share_models or model is not None) else "cliprunner-%d" % ClipRunner._tags
         self.cfg = cfg
         H, W = frame_hw
         _, key_sym, cur_sym = get_symbols(version, cfg)
@@ -90,12 +110,22 @@ class ClipRunner(object):
         provide = [[('data', (B, 3, H, W)), ('data_key', (B, 3, H, W)), ('feat_key', (B, 2048, 1, 1))]]
         self.key_predictor = Predictor(key_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
                                        provide_data=provide, provide_label=[None],
-                                       arg_params=arg_params, aux_params=aux_params, model=model)
+                                       arg_params=arg_params, aux_params=aux_params, model=model, owner=self.owner)
         self.cur_predictor = Predictor(cur_sym, self.data_names, [], context=ctx, max_data_shapes=max_shape,
                                        provide_data=provide, provide_label=[None],
-                                       arg_params=arg_params, aux_params=aux_params, model=model)
+                                       arg_params=arg_params, aux_params=aux_params, model=model, owner=self.owner)
         self.feat = None
         self.output_key = 'croped_score_output' if self.version in ('101', 'dff') else 'correction_output'
+
+    def close(self):
+        """release the models this runner owns (no-op for shared / explicit models)"""
+        if self.owner is not None:
+            from .core import tester
+            tester.release_models(self.owner)
+
+    def prefetch(self, arrays):
+        """start the upload of the NEXT frame's image (page-locked arrays only) beside the running forward"""
+        return self.key_predictor.prefetch(arrays[0])
 
     def step(self, idx, arrays, interval):
         """One frame (demo.py:235-245).  Returns (logits handle, label-map handle)."""
@@ -137,6 +167,9 @@ def main(argv=None):
     ap.add_argument('--synthetic', default='1024x2048')
     ap.add_argument('--params', nargs='*', default=[], help='MXNet .params checkpoints, merged in order')
     ap.add_argument('--out', default='', help='directory for palette PNGs seg_<frame>.png (demo.py:252-257)')
+    ap.add_argument('--pageable', action='store_true',
+                    help='frames in pageable host memory, uploaded synchronously inside each forward (the reference\'s '
+                         'loop one to one); default: page-locked frames, the next frame\'s upload overlaps the current forward')
     args = ap.parse_args(argv)
     version, interv, num_ex = str(args.version), args.interval, args.num_ex
     if version not in ['18', '34', '50', '101', 'dff']:
@@ -159,8 +192,7 @@ def main(argv=None):
         names = select_frames(names[:30 * num_ex], num_ex, interv, args.avg_acc)
         frames = [np.asarray(Image.open(n).convert('RGB'))[:, :, ::-1] for n in names]
         for lf in label_files:
-            c = os.path.basename(lf).split('_')
-            labels[(c[1], c[2])] = lf
+            labels[label_key(lf)] = lf
     else:
         from .utils import synth
         H, W = [int(v) for v in args.synthetic.split('x')]
@@ -183,7 +215,7 @@ def main(argv=None):
         print('no --params given: seeded random weights (throughput is valid, mIoU is meaningless)')
         arg_params, aux_params = synth.model_params(version, H, W, config)
 
-    data = build_batches(frames, config)
+    data = build_batches(frames, config, pinned=not args.pageable)
     runner = ClipRunner(version, config, arg_params, aux_params, (H, W))
     for j in range(min(2, len(data))):       # warm up (demo.py:207-220)
         runner.step(j, data[j], interv)[1].asnumpy()
@@ -193,6 +225,8 @@ def main(argv=None):
     for idx, arrays in enumerate(data):
         tic()
         _, lab = runner.step(idx, arrays, interv)
+        if idx + 1 < len(data) and not args.pageable:
+            runner.prefetch(data[idx + 1])        # next frame starts crossing PCIe while this one computes
         pred = np.uint8(np.squeeze(lab.asnumpy()))
         elapsed = toc()
         time_sum += elapsed
@@ -205,8 +239,7 @@ def main(argv=None):
             seg = Image.fromarray(pred)
             seg.putpalette(getpallete(256))
             seg.save(os.path.join(args.out, 'seg_' + os.path.basename(names[idx])))
-        comps = os.path.basename(names[idx]).split('_')
-        lf = labels.get((comps[1], comps[2])) if len(comps) > 2 else None
+        lf = labels.get(label_key(names[idx]))
         if lf is not None:
             from PIL import Image
             label = np.asarray(Image.open(lf))

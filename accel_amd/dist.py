@@ -49,18 +49,31 @@ def as_torch(ptr, shape, dtype="f4", device=0):
     return torch.as_tensor(_DevPtr(ptr, shape, {"f4": "<f4", "u1": "|u1"}[dtype]), device="cuda:%d" % device)
 
 
+def make_comm(ctx, group=None):
+    """RCCL communicator of the C ABI (accel_comm_create) spanning the ranks of a torch.distributed group: the 128-byte
+    unique id is made on rank 0 and handed to the others through the process group (the rendezvous torch.distributed
+    already did); everything after that is libaccel_hip + librccl, no torch on the data path."""
+    import torch.distributed as dist
+    from . import runtime
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [runtime.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return runtime.Comm(ctx, rank, world, box[0])
+
+
 class FrameGather(object):
     """Asynchronous gather of each frame's output (logits fp32 19xHxW, or the
     uint8 label map) to rank 0, overlapped with the next frame's compute.
 
-    Per frame: D2D copy of the model's output buffer into one of two staging
-    tensors on the compute stream (so the next frame may overwrite the output),
-    then `dist.gather(async_op=True)` issued with the compute stream current --
-    RCCL's stream waits for the copy and runs beside the next frame.  Each peer
-    uses its own direct xGMI link to the root, so the 7 sends of a step run
-    concurrently; no ring, no all-reduce."""
+    transport "cabi" (default on a GPU): accel_gather_logits of include/accel_hip.h -- the model's output buffer is
+    copied into one of two staging slots in compute-stream order (so the next frame may overwrite the output), RCCL
+    send/recv to the root run on the library's communication stream beside the next frame; each peer uses its own
+    direct xGMI link to the root, no ring, no all-reduce.
+    transport "torch": the same protocol through torch.distributed.gather(async_op=True) (fallback when librccl
+    cannot be resolved by the library; also the gloo/CPU path of the tests)."""
 
-    def __init__(self, model, ctx, what, shape, dtype, device, group=None, backend_device="cuda"):
+    def __init__(self, model, ctx, what, shape, dtype, device, group=None, backend_device="cuda", transport="auto"):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -69,18 +82,36 @@ class FrameGather(object):
         self.group = group
         tdt = {"f4": torch.float32, "u1": torch.uint8}[dtype]
         dev = "cuda:%d" % device if backend_device == "cuda" else "cpu"
-        self.stage = [torch.empty(shape, dtype=tdt, device=dev) for _ in range(2)]
+        self.on_cuda = backend_device == "cuda"
+        self.nbytes = int(np.prod(shape)) * (4 if dtype == "f4" else 1)
+        self.n = 0
+        self.comm, self.transport_note = None, ""
+        if self.on_cuda and transport in ("auto", "cabi"):
+            try:
+                self.comm = make_comm(ctx, group)
+            except Exception as e:          # librccl not resolvable from the library: same protocol through torch
+                if transport == "cabi":
+                    raise
+                self.transport_note = "C-ABI communicator unavailable (%s); torch.distributed transport" % (e,)
+        self.transport = "cabi" if self.comm is not None else "torch"
         self.recv = [[torch.empty(shape, dtype=tdt, device=dev) for _ in range(self.world)] for _ in range(2)] \
             if self.rank == 0 else [None, None]
+        if self.comm is not None:
+            # the root receives rank r's block at recv + r*nbytes: one contiguous tensor per slot, `recv` are views of it
+            self._flat = [torch.empty((self.world,) + tuple(shape), dtype=tdt, device=dev) for _ in range(2)] if self.rank == 0 else [None, None]
+            if self.rank == 0:
+                self.recv = [[self._flat[s][r] for r in range(self.world)] for s in range(2)]
+            self._src_ptr, _ = model.buffer(what)
+            return
+        self.stage = [torch.empty(shape, dtype=tdt, device=dev) for _ in range(2)]
         self.work = [None, None]
-        self.n = 0
-        self.on_cuda = backend_device == "cuda"
         self.stream = torch.cuda.ExternalStream(ctx.stream, device=dev) if self.on_cuda else None
-        self.nbytes = int(np.prod(shape)) * (4 if dtype == "f4" else 1)
 
     def submit(self):
         s = self.n & 1
-        if self.on_cuda:
+        if self.comm is not None:
+            self.comm.gather(self._src_ptr, self._flat[s].data_ptr() if self.rank == 0 else None, self.nbytes, 0)
+        elif self.on_cuda:
             with self.torch.cuda.stream(self.stream):
                 # stream-level wait (not a host block): the COMPUTE stream must not refill this staging
                 # slot before the gather issued from it two frames ago has read it
@@ -98,6 +129,9 @@ class FrameGather(object):
         return s
 
     def drain(self):
+        if self.comm is not None:
+            self.comm.sync()
+            return
         for s in (0, 1):
             if self.work[s] is not None:
                 if self.on_cuda:
@@ -112,3 +146,8 @@ class FrameGather(object):
     def last(self, slot):
         """Root only: list (one per rank) of the tensors gathered in `slot`."""
         return self.recv[slot]
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None

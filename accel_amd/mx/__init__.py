@@ -33,3 +33,8 @@ def gpu(i=0):
 
 def cpu(i=0):
     return Context("cpu", i)
+
+
+def cpu_pinned(i=0):
+    """mx.cpu_pinned(): host arrays in page-locked memory (fast, overlappable transfers to the GPU)"""
+    return Context("cpu_pinned", i)

@@ -4,16 +4,28 @@ A DeviceArray is either host data (numpy) or a reference to a buffer that
 lives in HBM inside a plan/model of the HIP runtime; `.asnumpy()` is the only
 synchronising call, like `mx.nd.NDArray.asnumpy()` in the reference's demo
 loop (dff_deeplab/demo.py:238,245)."""
+import itertools
+
 import numpy as np
+
+_UID = itertools.count(1)
 
 
 class DeviceArray(object):
-    def __init__(self, host=None, shape=None, fetch=None, device_ref=None, labels_of=None):
-        self._host = None if host is None else np.ascontiguousarray(host)
+    """Immutable once built (like an NDArray the harness never writes into): `uid` identifies the CONTENT, which is what
+    lets a Predictor recognise that the bytes of an input are already in HBM.  Host data is a private copy
+    (mx.nd.array copies, as MXNet does) and is handed out read-only."""
+
+    def __init__(self, host=None, shape=None, fetch=None, device_ref=None, labels_of=None, pinned=None):
+        self.uid = next(_UID)
+        self._host = host
+        if self._host is not None and self._host.flags.writeable:
+            self._host.setflags(write=False)
         self._shape = tuple(shape) if shape is not None else tuple(self._host.shape)
         self._fetch = fetch            # callable -> numpy (blocks)
-        self.device_ref = device_ref   # (owner, buffer name) when resident in HBM
+        self.device_ref = device_ref   # (owner model, buffer name, write generation) when resident in HBM
         self.labels_of = labels_of     # callable -> DeviceArray of the fused argmax, if any
+        self.pinned = pinned           # runtime.PinnedBuffer behind `_host` when built with ctx=mx.cpu_pinned()
 
     @property
     def shape(self):
@@ -23,9 +35,17 @@ class DeviceArray(object):
     def on_device(self):
         return self._host is None
 
+    @property
+    def has_host_copy(self):
+        return self._host is not None
+
     def asnumpy(self):
+        """Blocks until the data is on the host.  The array is read-only: copy it before editing (MXNet returns a
+        fresh copy on every call; one shared read-only copy keeps 160 MB logit maps from being duplicated)."""
         if self._host is None:
-            self._host = np.ascontiguousarray(self._fetch())
+            h = np.ascontiguousarray(self._fetch())
+            h.setflags(write=False)
+            self._host = h
         return self._host
 
     def __repr__(self):
@@ -34,9 +54,17 @@ class DeviceArray(object):
 
 
 def array(src, ctx=None, dtype=np.float32):
+    """mx.nd.array: always a COPY of `src` (later edits of `src` do not reach the array).  With
+    ctx=mx.cpu_pinned() the copy lives in page-locked memory, the source of overlapped uploads."""
     if isinstance(src, DeviceArray):
         return src
-    return DeviceArray(host=np.asarray(src, dtype=dtype))
+    a = np.asarray(src)
+    if ctx is not None and getattr(ctx, "device_type", "") == "cpu_pinned":
+        from .. import runtime
+        pb = runtime.PinnedBuffer(a.shape, dtype)
+        pb.array[...] = a
+        return DeviceArray(host=pb.array, pinned=pb)
+    return DeviceArray(host=np.array(a, dtype=dtype, order="C", copy=True))
 
 
 def zeros(shape, ctx=None, dtype=np.float32):

@@ -60,6 +60,17 @@ def _declare(lib):
         "accel_model_write": [vp, c.c_char_p, vp, sz, i],
         "accel_model_read": [vp, c.c_char_p, vp, sz, i],
         "accel_model_buffer": [vp, c.c_char_p, c.POINTER(vp), c.POINTER(sz)],
+        "accel_model_buffer_generation": [vp, c.c_char_p, c.POINTER(c.c_uint64)],
+        "accel_host_alloc": [sz, c.POINTER(vp)],
+        "accel_host_free": [vp],
+        "accel_model_prefetch": [vp, c.c_char_p, vp, sz],
+        "accel_model_commit": [vp, c.c_char_p],
+        "accel_model_read_async": [vp, c.c_char_p, vp, sz],
+        "accel_comm_unique_id": [vp],
+        "accel_comm_create": [vp, i, i, vp, c.POINTER(vp)],
+        "accel_comm_destroy": [vp],
+        "accel_gather_logits": [vp, vp, vp, sz, i],
+        "accel_comm_sync": [vp],
         "accel_key_forward": [vp, vp, i, vp, vp, vp, i],
         "accel_cur_forward": [vp, vp, vp, i, vp, vp, vp, i],
         "accel_conv2d": [vp, vp, i, i, i, i, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp, vp, i, f, i, vp],
@@ -207,6 +218,63 @@ class Context(object):
         return out
 
 
+class PinnedBuffer(object):
+    """Page-locked host memory (accel_host_alloc) seen as a numpy array: the source of accel_model_prefetch and the
+    destination of accel_model_read_async.  Freed with the object."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._ptr = ctypes.c_void_p()
+        check(lib().accel_host_alloc(max(self.nbytes, 1), ctypes.byref(self._ptr)))
+        raw = (ctypes.c_char * max(self.nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            lib().accel_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm(object):
+    """RCCL communicator of the C ABI (accel_comm_*): one per process/GPU; `gather` is accel_gather_logits."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().accel_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, rank, nranks, unique_id):
+        self.ctx, self.rank, self.nranks = ctx, int(rank), int(nranks)
+        self.handle = ctypes.c_void_p()
+        idb = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(lib().accel_comm_create(ctx.handle, self.rank, self.nranks, idb, ctypes.byref(self.handle)))
+
+    def gather(self, send_ptr, recv_ptr, nbytes, root=0):
+        check(lib().accel_gather_logits(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr) if recv_ptr else None,
+                                        int(nbytes), int(root)))
+
+    def sync(self):
+        check(lib().accel_comm_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().accel_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
 class Plan(object):
     def __init__(self, model, handle, role):
         self.model, self.handle, self.role = model, handle, role
@@ -284,6 +352,24 @@ class Model(object):
         ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
         check(lib().accel_model_buffer(self.handle, buf.encode(), ctypes.byref(ptr), ctypes.byref(n)))
         return ptr.value, n.value
+
+    def generation(self, buf):
+        """write generation of a persistent buffer (accel_model_buffer_generation)"""
+        g = ctypes.c_uint64()
+        check(lib().accel_model_buffer_generation(self.handle, buf.encode(), ctypes.byref(g)))
+        return int(g.value)
+
+    def prefetch(self, buf, pinned):
+        """enqueue the upload of a PinnedBuffer into the shadow of `buf` on the copy stream (overlaps the running plan)"""
+        check(lib().accel_model_prefetch(self.handle, buf.encode(), pinned.ptr, pinned.nbytes))
+
+    def commit(self, buf):
+        self.__dict__.get("_resident", {}).pop(buf, None)
+        check(lib().accel_model_commit(self.handle, buf.encode()))
+
+    def read_async(self, buf, pinned):
+        """enqueue the download of `buf` into a PinnedBuffer on the compute stream; valid after ctx.sync()"""
+        check(lib().accel_model_read_async(self.handle, buf.encode(), pinned.ptr, pinned.nbytes))
 
     def _outs(self, want, H, W, ncls=19):
         feat = np.empty((1, 2048, H // 16, W // 16), np.float32) if "feat" in want else None

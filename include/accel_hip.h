@@ -42,6 +42,7 @@ typedef struct accel_plan accel_plan;     /* one bound graph (key or cur)       
 #define ACCEL_ERR_HIP (-2)
 #define ACCEL_ERR_PLAN (-3)
 #define ACCEL_ERR_PARAM (-4)
+#define ACCEL_ERR_COMM (-5)
 
 const char* accel_last_error(void);
 const char* accel_version(void);
@@ -93,6 +94,28 @@ int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);
 int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device);
 int accel_model_read(accel_model* m, const char* buf, void* dst, size_t bytes, int dst_on_device);
 int accel_model_buffer(accel_model* m, const char* buf, void** dev_ptr, size_t* bytes);
+/* Write generation of a persistent buffer: starts at 0, bumped by every accel_plan_run of a plan that writes the
+ * buffer, every accel_model_write / accel_model_commit into it and every raw-pointer hand-out.  A device handle to an
+ * output (the `feat` a Predictor returns, tester.py:158-171) records the generation it was produced at; a consumer
+ * that finds another generation knows the bytes are no longer that output (MXNet: "outputs are valid until the next
+ * forward") and must fall back to a host copy or fail -- never read whatever the buffer holds now. */
+int accel_model_buffer_generation(accel_model* m, const char* buf, uint64_t* generation);
+
+/* ---- host I/O overlapped with compute ------------------------------------------------------------------------------
+ * The reference's timed loop (demo.py:234-250) moves the frame in and the label map out synchronously through pageable
+ * memory.  Here: page-locked staging memory, the NEXT frame's upload on a copy stream while the current frame computes,
+ * and an asynchronous download of the outputs.
+ *   accel_host_alloc / _free      page-locked host memory (hipHostMalloc)
+ *   accel_model_prefetch(buf,src) enqueue H2D of `src` (page-locked, must stay valid until the matching commit) into a
+ *                                 library-owned shadow of `buf` on the copy stream; returns immediately
+ *   accel_model_commit(buf)       compute stream waits for the prefetch and copies the shadow into `buf` (HBM to HBM)
+ *   accel_model_read_async        enqueue D2H of `buf` into page-locked `dst` on the compute stream, no host wait:
+ *                                 the bytes are valid after accel_sync() */
+int accel_host_alloc(size_t bytes, void** out);
+int accel_host_free(void* p);
+int accel_model_prefetch(accel_model* m, const char* buf, const void* pinned_src, size_t bytes);
+int accel_model_commit(accel_model* m, const char* buf);
+int accel_model_read_async(accel_model* m, const char* buf, void* pinned_dst, size_t bytes);
 
 /* whole-frame entry points, the two Predictor.predict calls of the demo loop
  * (demo.py:235-245; tester.py:158-171 im_segment).  img_*: fp32 1x3xHxW already
@@ -109,7 +132,9 @@ int accel_cur_forward(accel_model* m, const float* img_cur, const float* img_pre
  * same weight repacking as the plans.  N >= 1 for conv / deconv / deformable conv / pool (the
  * convolution kernel runs the batch as one GEMM with M = N*Ho*Wo). */
 /* mx.symbol.Convolution (+ optional per-channel scale/shift, residual, activation:
- * the fused epilogue).  act: 0 none, 1 relu, 2 leaky(slope). */
+ * the fused epilogue).  act: 0 none, 1 relu, 2 leaky(slope).  force_tile: -1 = the library's choice, otherwise a launch
+ * geometry id of conv_igemm.hip (every accepted id computes the same contraction; ids the build does not carry are
+ * rejected with ACCEL_ERR_ARG -- timing-only ablation variants exist only in the diagnostics build). */
 int accel_conv2d(accel_ctx* ctx, const float* x, int N, int C, int H, int W,
                  const float* w, const float* bias, int K, int kh, int kw,
                  int sh, int sw, int ph, int pw, int dh, int dw,
@@ -137,6 +162,28 @@ int accel_score_fuse(accel_ctx* ctx, const float* left, const float* right, int 
 int accel_argmax_c(accel_ctx* ctx, const float* logits, int C, int H, int W, uint8_t* labels);
 /* FlowNet input stage: avgpool2(concat(cur/255, prev/255)) -> 6 x H/2 x W/2 */
 int accel_flow_input(accel_ctx* ctx, const float* cur, const float* prev, int H, int W, float* out);
+
+/* ---- multi-GPU: the one collective of the path -------------------------------------------------------
+ * Clips are sharded over ranks with no activation exchange; each frame's logits (or label map) are gathered to a root
+ * rank.  Stands in for the host-side merge of per-GPU results in the reference's multi-GPU tester
+ * (dff_rfcn/function/test_rcnn.py:62-82, dff_rfcn/core/tester.py:290-298: one thread per GPU, results appended on the
+ * host).  One process per GPU; RCCL (librccl, resolved at run time) point-to-point send/recv over xGMI: every peer
+ * uses its own direct link to the root, no ring.
+ *   accel_comm_unique_id   128-byte id, made on one rank and distributed by the caller (file, socket, torch.distributed)
+ *   accel_comm_create      communicator of `nranks` processes, this one being `rank`, bound to ctx's device; owns a
+ *                          communication stream and two staging slots
+ *   accel_gather_logits    every rank contributes `bytes` at `sendbuf` (HBM); the root receives rank r's block at
+ *                          recvbuf + r*bytes (recvbuf is NULL on the other ranks).  Asynchronous: sendbuf is copied
+ *                          into a staging slot in compute-stream order (so the next frame may overwrite it at once), the
+ *                          transfer runs on the communication stream beside the next frame's kernels.  recvbuf must
+ *                          stay untouched until accel_comm_sync() or the second-next gather.
+ *   accel_comm_sync        host wait for all gathers issued so far */
+typedef struct accel_comm accel_comm;
+int accel_comm_unique_id(void* id128);
+int accel_comm_create(accel_ctx* ctx, int rank, int nranks, const void* id128, accel_comm** out);
+int accel_comm_destroy(accel_comm* comm);
+int accel_gather_logits(accel_comm* comm, const void* sendbuf, void* recvbuf_or_null, size_t bytes, int root);
+int accel_comm_sync(accel_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -117,10 +117,12 @@ def test_config3_accel101_full_size_properties_1024x2048(demo_cfg):
         np.testing.assert_array_equal(lg_c2.asnumpy(), c_logits)
         lg_k3, _ = r.step(2, data[1], 1)
         np.testing.assert_array_equal(lg_k3.asnumpy(), a_logits)
-        assert np.isfinite(c_logits).all() and len(np.unique(c_labels)) > 1
+        # (seeded random weights give Accel-101 one dominant class at this size, so the label map may be constant:
+        # the non-triviality checks are on the logits)
+        assert np.isfinite(c_logits).all() and float(c_logits.std(axis=(2, 3)).min()) > 0
         # Accel-101's non-key frame is a different function of the frame than the key graph (feature fusion
-        # 4096 -> 2048 on top of the warped feature): the two label maps must not be trivially equal
-        assert float((c_labels != a_labels).mean()) > 0
+        # 4096 -> 2048 on top of the warped feature): the two logit maps must not be trivially equal
+        assert float(np.abs(c_logits - a_logits).max()) > 1e-3
     finally:
         tester.release_models()
 
@@ -133,9 +135,11 @@ def _free_port():
     return p
 
 
-def test_config4_rccl_gather_on_one_gpu(demo_cfg):
-    """FrameGather over RCCL (backend "nccl") with a world of one rank: the gathered tensor of every frame must be
-    byte-identical to the model's logits / labels buffer, across more frames than staging slots."""
+@pytest.mark.parametrize("transport", ["cabi", "torch"])
+def test_config4_rccl_gather_on_one_gpu(demo_cfg, transport):
+    """FrameGather over RCCL with a world of one rank -- through accel_gather_logits of the C ABI ("cabi": libaccel_hip
+    + librccl, the default) and through torch.distributed ("torch", the fallback): the gathered tensor of every frame
+    must be byte-identical to the model's logits / labels buffer, across more frames than staging slots."""
     import torch
     import torch.distributed as dist
     from accel_amd import demo, dist as adist
@@ -152,8 +156,9 @@ def test_config4_rccl_gather_on_one_gpu(demo_cfg):
         data = demo.build_batches(frames, demo_cfg)
         r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
         m = r.key_predictor._model
-        g_logits = adist.FrameGather(m, m.ctx, "logits", (1, 19, H, W), "f4", 0)
-        g_labels = adist.FrameGather(m, m.ctx, "labels", (1, H, W), "u1", 0)
+        g_logits = adist.FrameGather(m, m.ctx, "logits", (1, 19, H, W), "f4", 0, transport=transport)
+        g_labels = adist.FrameGather(m, m.ctx, "labels", (1, H, W), "u1", 0, transport=transport)
+        assert g_logits.transport == transport
         for t in range(4):
             lg, lab = r.step(t, data[t], interval)
             s0, s1 = g_logits.submit(), g_labels.submit()
@@ -161,9 +166,34 @@ def test_config4_rccl_gather_on_one_gpu(demo_cfg):
             g_labels.drain()
             np.testing.assert_array_equal(g_logits.last(s0)[0].cpu().numpy(), lg.asnumpy())
             np.testing.assert_array_equal(g_labels.last(s1)[0].cpu().numpy(), np.uint8(lab.asnumpy()))
+        g_logits.close()
+        g_labels.close()
     finally:
         tester.release_models()
         dist.destroy_process_group()
+
+
+def test_cabi_gather_without_torch_distributed(ctx):
+    """accel_comm_* / accel_gather_logits stand-alone (a C host would do exactly this): one rank, the root's receive
+    buffer must hold the send buffer's bytes; the send buffer may be overwritten right after the call returns."""
+    import torch
+    from accel_amd import runtime
+    comm = runtime.Comm(ctx, 0, 1, runtime.Comm.unique_id())
+    try:
+        st = torch.cuda.ExternalStream(ctx.stream, device="cuda:0")
+        with torch.cuda.stream(st):
+            send = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+            recv = [torch.zeros_like(send) for _ in range(2)]
+            for it in range(5):
+                send.add_(1.0)                                   # compute-stream work producing the frame's output
+                comm.gather(send.data_ptr(), recv[it & 1].data_ptr(), send.numel() * 4, 0)
+            send.zero_()                                         # overwritten at once: staging holds what is in flight
+        comm.sync()
+        ctx.sync()
+        base = torch.arange(1 << 20, dtype=torch.float32)
+        assert torch.equal(recv[0].cpu(), base + 5.0) and torch.equal(recv[1].cpu(), base + 4.0)
+    finally:
+        comm.close()
 
 
 def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):

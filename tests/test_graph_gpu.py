@@ -220,10 +220,14 @@ def test_size_not_multiple_of_128_is_rejected(demo_cfg):
 
 def test_two_resolutions_in_one_process(demo_cfg):
     """a second frame size re-lowers and binds its own model (MutableModule rebinds on a shape change,
-    module.py:1026-1042); results of the first size are unaffected"""
+    module.py:1026-1042); results of the first size are unaffected, and the lazily bound size is CORRECT from its first
+    non-key frame on: the cur plan of the new size is finalized (autotuned, warmed up, captured) between the key frame
+    and the first non-key frame of the clip, which must not disturb the propagated feature."""
     from accel_amd import demo
     from accel_amd.core import tester
     arg, aux = synth.model_params("18", 128, 256, demo_cfg)
+    P = dict(arg)
+    P.update(aux)
     try:
         outs = {}
         for (H, W) in ((128, 256), (256, 256), (128, 256)):
@@ -233,12 +237,14 @@ def test_two_resolutions_in_one_process(demo_cfg):
             r = outs.setdefault("runner", demo.ClipRunner("18", demo_cfg, arg, aux, (128, 256)))
             res = []
             for i in range(2):
-                lg, _ = r.step(i, data[i], 2)
-                res.append(lg.asnumpy().copy())
+                lg, lab = r.step(i, data[i], 2)
+                res.append((lg.asnumpy().copy(), np.uint8(lab.asnumpy()[0])))
             outs.setdefault((H, W), []).append(res)
+            if (H, W) == (256, 256):
+                _check(res, G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), 2), "accel-18 lazily bound 256x256")
         a, b = outs[(128, 256)]
-        np.testing.assert_array_equal(a[1], b[1])
-        assert outs[(256, 256)][0][1].shape == (1, 19, 256, 256)
+        np.testing.assert_array_equal(a[1][0], b[1][0])
+        assert outs[(256, 256)][0][1][0].shape == (1, 19, 256, 256)
     finally:
         tester.release_models()
 
@@ -273,9 +279,10 @@ def test_c_abi_frame_entry_points(demo_cfg):
 
 
 def test_resident_input_reuse_is_invisible(demo_cfg):
-    """Predictor.predict skips the PCIe copy of an input that is already in HBM (data_key = the previous call's data
-    array).  Results must be bit-identical to feeding fresh copies, and an in-place edit of a host array that keeps
-    its identity must be noticed."""
+    """Predictor.predict skips the PCIe copy of an input that is already in HBM (data_key = the array the previous call
+    uploaded as data).  Results must be bit-identical to feeding fresh copies; arrays are immutable copies of their
+    source (mx.nd.array copies like MXNet), so an edit of the source after the array was built must not leak in, and an
+    edit through asnumpy() is refused."""
     from accel_amd import demo, mx
     from accel_amd.core import tester
     H, W = 128, 256
@@ -283,7 +290,7 @@ def test_resident_input_reuse_is_invisible(demo_cfg):
     arg, aux = synth.model_params("18", H, W, demo_cfg)
     frames = synth.make_clip(H, W, 3)
     data = demo.build_batches(frames, demo_cfg)
-    assert data[1][1].asnumpy() is data[0][0].asnumpy()   # the reuse precondition the demo loop creates (one host image, two handles)
+    assert data[1][1] is data[0][0]          # the reuse precondition the demo loop creates (one array, two roles)
     try:
         r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
         a = [r.step(i, data[i], 3)[0].asnumpy().copy() for i in range(3)]
@@ -291,15 +298,99 @@ def test_resident_input_reuse_is_invisible(demo_cfg):
         b = [r.step(i, fresh[i], 3)[0].asnumpy().copy() for i in range(3)]
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
+        src = data[2][0].asnumpy().copy()
+        arr = mx.nd.array(src)
+        src += 3.0                                       # the source changes after the array was built: no effect
         r.step(0, data[0], 3)
         r.step(1, data[1], 3)
-        data[2][0].asnumpy()[...] += 3.0                # same object, new content
-        c = r.step(2, data[2], 3)[0].asnumpy().copy()
-        assert float(np.abs(c - a[2]).max()) > 1e-3
+        c = r.step(2, [arr, data[2][1], data[2][2]], 3)[0].asnumpy()
+        np.testing.assert_array_equal(c, a[2])
+        with pytest.raises(ValueError):
+            arr.asnumpy()[...] += 1.0                    # handed out read-only
         r.step(0, data[0], 3)
         r.step(1, data[1], 3)
-        d = r.step(2, [mx.nd.array(data[2][0].asnumpy().copy()), fresh[2][1], fresh[2][2]], 3)[0].asnumpy()
-        np.testing.assert_array_equal(c, d)
+        d = r.step(2, [mx.nd.array(src), data[2][1], data[2][2]], 3)[0].asnumpy()      # new content, new array
+        assert float(np.abs(d - a[2]).max()) > 1e-3
+    finally:
+        tester.release_models()
+
+
+def test_pinned_prefetch_pipeline_is_invisible(demo_cfg):
+    """Page-locked frames with the next frame's upload started beside the running forward (ClipRunner.prefetch ->
+    accel_model_prefetch / accel_model_commit) give the same logits as the plain synchronous loop."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W = 128, 256
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 5)
+    try:
+        plain = demo.build_batches(frames, demo_cfg)
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        ref = [r.step(i, plain[i], 3)[0].asnumpy().copy() for i in range(5)]
+        pinned = demo.build_batches(frames, demo_cfg, pinned=True)
+        assert pinned[0][0].pinned is not None
+        got = []
+        for i in range(5):
+            lg, lab = r.step(i, pinned[i], 3)
+            if i + 1 < 5:
+                assert r.prefetch(pinned[i + 1])
+            got.append((lg.asnumpy().copy(), lab.asnumpy().copy()))
+        for (x, lab), y in zip(got, ref):
+            np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(lab[0], np.argmax(x[0], axis=0))
+        # a prefetched frame that is NOT the one fed next must not be used
+        r.step(0, pinned[0], 3)
+        r.prefetch(pinned[3])
+        lg = r.step(1, pinned[1], 3)[0].asnumpy()
+        np.testing.assert_array_equal(lg, ref[1])
+    finally:
+        tester.release_models()
+
+
+def test_stale_feature_handle_is_never_read_silently(demo_cfg):
+    """A feature handle is valid until the next forward that writes the propagated feature.  Reusing an older handle
+    (DFF-style: the key feature for several non-key frames) must either use the handle's host copy or fail -- and two
+    runners interleaving clips of the same size must not see each other's feature."""
+    from accel_amd import demo, runtime
+    from accel_amd.core import tester
+    H, W = 128, 256
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    A = demo.build_batches(synth.make_clip(H, W, 3, seed=5), demo_cfg)
+    B = demo.build_batches(synth.make_clip(H, W, 3, seed=6), demo_cfg)
+    try:
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        ref = [r.step(i, A[i], 3)[0].asnumpy().copy() for i in range(3)]
+        # (1) stale handle without a host copy: refused
+        r.step(0, A[0], 3)
+        key_feat = r.feat
+        r.step(1, A[1], 3)                      # warps `feat` in place: key_feat no longer describes the buffer
+        r.feat = key_feat
+        with pytest.raises(runtime.AccelError, match="overwritten"):
+            r.step(2, A[2], 3)
+        with pytest.raises(runtime.AccelError, match="stale"):
+            key_feat.asnumpy()
+        # (2) the same pattern with a host copy taken in time: the copy is uploaded, result = warping the KEY feature
+        r.step(0, A[0], 3)
+        key_feat = r.feat
+        key_host = key_feat.asnumpy().copy()
+        r.step(1, A[1], 3)
+        r.feat = key_feat                       # has a host copy now
+        dff_style = r.step(2, A[2], 3)[0].asnumpy().copy()
+        r.step(0, A[0], 3)
+        from accel_amd import mx
+        r.feat = mx.nd.array(key_host)
+        expect = r.step(2, A[2], 3)[0].asnumpy()
+        np.testing.assert_allclose(dff_style, expect, rtol=0, atol=1e-5 * max(1.0, float(np.abs(expect).max())))
+        # (3) two runners, same size and weights, clips interleaved frame by frame
+        r2 = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        refB = [r2.step(i, B[i], 3)[0].asnumpy().copy() for i in range(3)]
+        for i in range(3):
+            a = r.step(i, A[i], 3)[0].asnumpy().copy()
+            b = r2.step(i, B[i], 3)[0].asnumpy().copy()
+            np.testing.assert_array_equal(a, ref[i])
+            np.testing.assert_array_equal(b, refB[i])
     finally:
         tester.release_models()
 

@@ -441,3 +441,45 @@ def test_batched_lowering_scales_buffers_and_work(demo_cfg):
     conv1 = [a for k, a in l1.ops if k == "conv"][3]
     convB = [a for k, a in lB.ops if k == "conv"][3]
     assert float(convB["bytes"]) < 3 * float(conv1["bytes"])      # the weights are read once per launch
+
+
+def test_label_lookup_keeps_the_city():
+    """Cityscapes val holds lindau_0000NN_000019 and munster_0000NN_000019 for the same NN: the ground-truth lookup of
+    the demo must key on (city, sequence, frame), or every lindau frame is scored against a munster label."""
+    from accel_amd import demo
+    files = ["/d/gtFine/val/lindau/lindau_000003_000019_gtFine_labelTrainIds.png",
+             "/d/gtFine/val/munster/munster_000003_000019_gtFine_labelTrainIds.png",
+             "/d/gtFine/val/frankfurt/frankfurt_000001_000019_gtFine_labelTrainIds.png"]
+    table = {demo.label_key(f): f for f in files}
+    assert len(table) == 3
+    assert table[demo.label_key("/d/leftImg8bit_sequence/val/lindau/lindau_000003_000019_leftImg8bit.png")] == files[0]
+    assert table[demo.label_key("/d/leftImg8bit_sequence/val/munster/munster_000003_000019_leftImg8bit.png")] == files[1]
+    assert demo.label_key("/d/leftImg8bit_sequence/val/lindau/lindau_000003_000018_leftImg8bit.png") not in table
+    assert demo.label_key("weird.png") is None
+
+
+def test_nd_array_copies_and_is_immutable():
+    """mx.nd.array copies its source (MXNet semantics) and hands host data out read-only; every array has its own uid,
+    which is what input residency in HBM is keyed on"""
+    from accel_amd import mx
+    src = np.arange(12, dtype=np.float64).reshape(3, 4)
+    a = mx.nd.array(src)
+    src += 100.0
+    assert a.asnumpy().dtype == np.float32 and float(a.asnumpy()[0, 1]) == 1.0
+    with pytest.raises(ValueError):
+        a.asnumpy()[0, 0] = 5.0
+    b = mx.nd.array(src)
+    assert a.uid != b.uid and mx.nd.array(a) is a
+
+
+def test_params_token_is_content_keyed():
+    """two predictors share a model only when their parameters are the same bytes (not the same dict object)"""
+    from accel_amd.core.tester import params_token
+    a = {"w": np.ones((2, 3), np.float32), "b": np.zeros(3, np.float32)}
+    b = {"b": np.zeros(3, np.float32), "w": np.ones((2, 3), np.float32)}       # another dict, other order, same content
+    assert params_token(a) == params_token(b)
+    b["w"] = b["w"].copy()
+    b["w"][1, 2] = 1.0000001
+    assert params_token(a) != params_token(b)
+    assert params_token(a, {}) == params_token(a) and params_token({"w": a["w"]}) != params_token({"v": a["w"]})
+    assert params_token({"w": np.ones((3, 2), np.float32)}) != params_token({"w": np.ones((2, 3), np.float32)})
