@@ -220,8 +220,9 @@ class Predictor(object):
         m = self._model
 
         def labels():
-            # mx.ndarray.argmax returns float indices; the fused kernel wrote uint8 labels
-            return DeviceArray(shape=(N, H, W), fetch=lambda: m.read("labels", (N, H, W), np.uint8).astype(np.float32),
+            # mx.ndarray.argmax returns float indices that the harness casts to uint8 at once (demo.py:245-246); the
+            # fused kernel wrote uint8 labels, and they are handed over as they are (no 4x wider host copy per frame)
+            return DeviceArray(shape=(N, H, W), fetch=lambda: m.read("labels", (N, H, W), np.uint8),
                                device_ref=(m, "labels", m.generation("labels")))
         return DeviceArray(shape=(N, ncls, H, W), fetch=lambda: m.read("logits", (N, ncls, H, W)),
                            device_ref=(m, "logits", m.generation("logits")), labels_of=labels)

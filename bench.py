@@ -11,7 +11,11 @@ branch, two heads, fused upsample+correction+argmax).  Frames are synthetic,
 weights seeded random (no checkpoints/data offline); the clip is resident in
 HBM before the timed region; outputs (fp32 logits + uint8 labels) stay in HBM;
 with N > 1 every frame's logits are gathered to rank 0 over RCCL, overlapped.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the same line carries `secondary` measurements taken with the same harness
+(--secondary none skips them): Accel-101 (the other model BASELINE.json's metric names), Accel-18 at one clip per call
+(the reference's TEST.BATCH_IMAGES: 1), and the PCIe-inclusive rate of the reference's own timing definition
+(demo.py:234-250: host frame in, forward, label map back on the host) through page-locked, double-buffered transfers.
+`vs_baseline` compares like with like: the PCIe-inclusive batch-1 rate against the reference's published K80 number.
 """
 import argparse
 import json
@@ -41,11 +45,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "8")),
                     help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
                          "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("ACCEL_BENCH_LANES", "1")),
-                    help="independent clip pipelines per GPU (own model, buffers and streams each)")
     ap.add_argument("--dtype", default=os.environ.get("ACCEL_CONV_DTYPE", "f32"), choices=["f32", "f16"],
                     help="f32 (default, the reference's precision: the headline) or f16 = fp16-MFMA convolutions with fp32 "
                          "storage/accumulate (BASELINE config 5; NOT the headline metric)")
+    ap.add_argument("--secondary", default="auto", choices=["auto", "none"],
+                    help="auto: on a single GPU with the headline configuration also measure Accel-101, batch 1 and the "
+                         "PCIe-inclusive loop (reported under `secondary`); none: headline only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -105,6 +110,139 @@ def main():
     finish()
 
 
+class Workload(object):
+    """Accel-<version> on this GPU, B clips per call, the clips (interval frames each) resident in HBM."""
+
+    def __init__(self, version, B, H, W, interval, local_rank, rank, config):
+        import torch
+        from accel_amd import demo, runtime
+        from accel_amd.utils import image, synth
+        self.version, self.B, self.H, self.W, self.interval = str(version), B, H, W, interval
+        self.config, self.local_rank, self.torch = config, local_rank, torch
+        self.arg, self.aux = synth.model_params(version, H, W, config)
+        self.model = runtime.Model(runtime.Context(local_rank))
+        self.runner = demo.ClipRunner(version, config, self.arg, self.aux, (H, W), context=[demo.mx.gpu(local_rank)],
+                                      model=self.model, batch=B)
+        self.key, _ = self.runner.key_predictor.plan_for(H, W, B)
+        self.cur, _ = self.runner.cur_predictor.plan_for(H, W, B)
+        # B clips, distinct per rank and clip: frames[t] = frame t of every clip, (B, 3, H, W) fp32, mean-subtracted
+        clips = [synth.make_clip(H, W, interval, seed=20260929 + rank * 64 + b) for b in range(B)]
+        self.host_frames = [np.concatenate([image.transform(c[t], config.network.PIXEL_MEANS).astype(np.float32) for c in clips], axis=0)
+                            for t in range(interval)]
+        self.dev_frames = [torch.from_numpy(f).cuda() for f in self.host_frames]
+        self.nbytes = B * 3 * H * W * 4
+        self.gather = None
+
+    def step(self):
+        """one clip per lane: key frame + (interval - 1) non-key frames, inputs and outputs in HBM"""
+        m = self.model
+        for t in range(self.interval):
+            m.write_device("data", self.dev_frames[t].data_ptr(), self.nbytes)
+            if t == 0:
+                self.key.run()
+            else:
+                m.write_device("data_key", self.dev_frames[t - 1].data_ptr(), self.nbytes)
+                self.cur.run()
+            if self.gather is not None:
+                self.gather.submit()
+
+    def sync(self):
+        if self.gather is not None:
+            self.gather.drain()
+        self.model.ctx.sync()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, dist=None):
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        if dist is not None:
+            dist.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        if dist is not None:
+            dist.barrier()
+        self.sync()
+        return time.perf_counter() - t0
+
+    def timed_pcie(self, steps, warmup):
+        """The reference's timing definition (demo.py:234-250): per frame, the image comes from host memory, the
+        forward runs, the label map arrives on the host -- through the Predictor / im_segment surface, with page-locked
+        frames and the NEXT frame's upload started beside the running forward (Predictor.prefetch)."""
+        from accel_amd import mx
+        ctx = mx.cpu_pinned()
+        arrs = [mx.nd.array(f, ctx=ctx) for f in self.host_frames]
+        zero = mx.nd.array(np.zeros((self.B, 2048, 1, 1), np.float32))
+        batches = [[arrs[t], arrs[t - 1] if t else arrs[0], zero] for t in range(self.interval)]
+        n = self.interval
+
+        def clip():
+            for t in range(n):
+                _, lab = self.runner.step(t, batches[t], n)
+                self.runner.prefetch(batches[(t + 1) % n])
+                host = lab.asnumpy()
+            return host
+        for _ in range(warmup):
+            clip()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = clip()
+        self.sync()
+        el = time.perf_counter() - t0
+        assert last.shape == (self.B, self.H, self.W)
+        return el
+
+    def conv_roofline(self, dtype):
+        """dominant kernel = the implicit-GEMM convolution: a HIP-event pair around every launch on the compute stream
+        (accel_plan_profile), all conv launches of one clip (1 key + interval-1 non-key plans)"""
+        kms, cms = self.key.profile(2), self.cur.profile(2)
+        fl = ms = n = by = 0.0
+        for plan, t, wgt in ((self.key, kms, 1), (self.cur, cms, self.interval - 1)):
+            for op, d in zip(plan.ops(), t):
+                if op["kind"] == "conv":
+                    fl += wgt * op["flops"]
+                    by += wgt * op["bytes"]
+                    ms += wgt * float(d)
+                    n += wgt
+        clip_ms = float(kms.sum()) + (self.interval - 1) * float(cms.sum())
+        ach = fl / (ms * 1e-3) / 1e12
+        peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "traffic_note": None, "algorithmic_bytes_per_launch": round(by / n),
+                "kernel": "conv_igemm_f32_kernel (all tile variants)" if dtype == "f32" else "conv_igemm_f16_kernel",
+                "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
+                "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)}
+
+    def close(self):
+        if self.gather is not None:
+            try:
+                self.gather.close()
+            except Exception:
+                pass
+        self.model.close()
+        self.model.ctx.close()
+        self.dev_frames = None
+
+
+def _pmc_traffic(version, H, W, interval, dtype, B):
+    """HBM bytes per conv launch from the committed PMC passes of this same command (counters cannot be read from
+    inside the process): only reported for the workload they were collected on."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_traffic.json")))
+    if not files or not (version == "18" and (H, W) == (1024, 2048) and interval == 5 and dtype == "f32"):
+        return None, None
+    with open(files[-1]) as f:
+        tr = json.load(f)
+    if int(tr.get("batch", 1)) != B:
+        return None, None
+    return (round(tr["read_bytes_per_launch"] + tr["write_bytes_per_launch"]),
+            "from the committed PMC passes (%s): %s" % (os.path.relpath(files[-1], HERE), tr["method"]))
+
+
 def _run(a):
     os.environ["ACCEL_CONV_DTYPE"] = a.dtype
     rank = int(os.environ.get("RANK", 0))
@@ -129,148 +267,115 @@ def _run(a):
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from accel_amd import demo, dist as adist, runtime
+    from accel_amd import dist as adist
     from accel_amd.config.config import config, update_config
-    from accel_amd.core import tester
-    from accel_amd.utils import image, synth
     update_config(os.path.join(HERE, "tests", "golden", "dff_deeplab_vid_demo.yaml"))
     config.SCALES[0] = (H, W)
 
-    arg, aux = synth.model_params(a.version, H, W, config)
-    # `lanes` independent clip pipelines per GPU: own model (weights, arena, buffers) and own HIP streams.
-    # Lane l runs its clips rotated by l * interval / lanes frames, so a key frame of one lane overlaps the
-    # non-key frames of the other (clips are independent: SURVEY.md 8e).
-    lanes = []
-    for l in range(max(1, a.lanes)):
-        model = runtime.Model(runtime.Context(local_rank))
-        runner = demo.ClipRunner(a.version, config, arg, aux, (H, W), context=[demo.mx.gpu(local_rank)], model=model, batch=B)
-        key_plan, _ = runner.key_predictor.plan_for(H, W, B)
-        cur_plan, _ = runner.cur_predictor.plan_for(H, W, B)
-        lanes.append({"model": model, "key": key_plan, "cur": cur_plan, "gather": None, "rot": (l * a.interval) // max(1, a.lanes)})
-    del arg, aux
-    model, key_plan, cur_plan = lanes[0]["model"], lanes[0]["key"], lanes[0]["cur"]
-
-    # B clips per step and lane, distinct per rank and clip, resident in HBM: dev_frames[t] = frame t of every clip
-    clips = [synth.make_clip(H, W, a.interval, seed=20260929 + rank * 64 + b) for b in range(B)]
-    dev_frames = [torch.from_numpy(np.concatenate([image.transform(c[t], config.network.PIXEL_MEANS).astype(np.float32) for c in clips], axis=0)).cuda()
-                  for t in range(a.interval)]
-    nbytes = B * 3 * H * W * 4
+    wl = Workload(a.version, B, H, W, a.interval, local_rank, rank, config)
 
     gather_note = "none (single GPU)"
     if (world > 1 or force_dist) and a.gather != "none":
         try:
-            for ln in lanes:
-                if a.gather == "logits":
-                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "logits", (B, 19, H, W), "f4", local_rank)
-                else:
-                    ln["gather"] = adist.FrameGather(ln["model"], ln["model"].ctx, "labels", (B, H, W), "u1", local_rank)
-            gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered" % a.gather
+            if a.gather == "logits":
+                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank)
+            else:
+                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank)
+            gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered, transport %s%s" % (
+                a.gather, wl.gather.transport, ("; " + wl.gather.transport_note) if wl.gather.transport_note else "")
         except Exception as e:   # keep the bench alive; the JSON says what happened
-            for ln in lanes:
-                ln["gather"] = None
+            wl.gather = None
             gather_note = "disabled: %r" % (e,)
 
     gather_failures = []
+    _step = wl.step
 
-    def step():
-        for i in range(a.interval):
-            for ln in lanes:
-                t = (i + ln["rot"]) % a.interval
-                m = ln["model"]
-                m.write_device("data", dev_frames[t].data_ptr(), nbytes)
-                if t == 0:
-                    ln["key"].run()
-                else:
-                    m.write_device("data_key", dev_frames[t - 1].data_ptr(), nbytes)
-                    ln["cur"].run()
-                if ln["gather"] is not None:
-                    try:
-                        ln["gather"].submit()
-                    except Exception as e:      # a failing collective must not cost the whole measurement
-                        ln["gather"] = None
-                        gather_failures.append(repr(e))
+    def guarded_step():
+        try:
+            _step()
+        except Exception as e:      # a failing collective must not cost the whole measurement
+            if wl.gather is None:
+                raise
+            wl.gather = None
+            gather_failures.append(repr(e))
+            _step()
+    wl.step = guarded_step
 
-    def sync():
-        for ln in lanes:
-            if ln["gather"] is not None:
-                ln["gather"].drain()
-            ln["model"].ctx.sync()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = wl.timed(a.steps, a.warmup, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    headline_cfg = a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32"
     out = None
     if rank == 0:
-        frames_total = world * a.steps * a.interval * len(lanes) * B
+        frames_total = world * a.steps * a.interval * B
         value = frames_total / elapsed
         out = {"metric": "frames/sec 1024x2048 Accel-%s kf=%d" % (a.version, a.interval), "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": round(value / K80_ACCEL18_FPS, 2) if (a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32") else None,
-               "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80 (includes H2D + label D2H)",
+               "vs_baseline": None,
+               "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80, batch 1, including H2D of the "
+                                "frame and D2H of the label map; vs_baseline = secondary.accel18_batch1_pcie_inclusive / that number "
+                                "(same timing definition, other hardware), null when that secondary was not measured",
                "dtype": "f32" if a.dtype == "f32" else "f16 operands on the matrix cores, f32 storage + accumulate (reduced precision: not the headline)",
                "data": "synthetic",
                "config": {"workload": "Accel-%s (R101-DCN key branch + FlowNet-S warp + R%s correction branch + fused score tail), "
                                       "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step, "
                                       "processed %d clips at a time (batched frames of independent clips)"
-                                      % (a.version, a.version, H, W, a.interval, len(lanes) * B, a.interval - 1, B),
-                          "frames_per_step_per_gpu": a.interval * len(lanes) * B, "clips_per_call": B, "clip_pipelines_per_gpu": len(lanes), "parallelism": "clip-sharded x%d (weights replicated)" % world,
+                                      % (a.version, a.version, H, W, a.interval, B, a.interval - 1, B),
+                          "frames_per_step_per_gpu": a.interval * B, "clips_per_call": B, "parallelism": "clip-sharded x%d (weights replicated)" % world,
                           "gather": gather_note + ("; DISABLED after failure: " + gather_failures[0] if gather_failures else ""), "weights": "seeded random",
                           "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
                                        "taken from the warped W_fc6*feat image of the key frame" if os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
                                        else "reference layer list one to one (ACCEL_FOLD_LINEAR=0)"), "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
     if rank == 0 and not a.no_roofline:
-        # dominant kernel = conv_igemm_f32 (implicit-GEMM conv on the fp32 matrix cores): HIP-event pair around
-        # every launch on the compute stream, all conv launches of one clip (1 key + 4 non-key plans)
-        kms, cms = key_plan.profile(2), cur_plan.profile(2)
-        fl = ms = n = by = 0.0
-        for plan, t, wgt in ((key_plan, kms, 1), (cur_plan, cms, a.interval - 1)):
-            for op, d in zip(plan.ops(), t):
-                if op["kind"] == "conv":
-                    fl += wgt * op["flops"]
-                    by += wgt * op["bytes"]
-                    ms += wgt * float(d)
-                    n += wgt
-        clip_ms = float(kms.sum()) + (a.interval - 1) * float(cms.sum())
-        ach = fl / (ms * 1e-3) / 1e12
-        peak = MFMA_F32_PEAK_TFLOPS if a.dtype == "f32" else 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
-        # HBM bytes per launch come from the committed PMC passes of this same command (counters cannot be read
-        # from inside the process): only reported for the workload they were collected on
-        traffic, traffic_note = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tj) and a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32" and len(lanes) == 1:
-            with open(tj) as f:
-                tr = json.load(f)
-        else:
-            tr = None
-        if tr is not None and int(tr.get("batch", 1)) == B:
-            traffic = round(tr["read_bytes_per_launch"] + tr["write_bytes_per_launch"])
-            traffic_note = "bytes per launch, profiles/r01_pmc_traffic.json: " + tr["method"]
-        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                           "algorithmic_bytes_per_launch": round(by / n),
-                           "kernel": "conv_igemm_f32_kernel (all tile variants)", "launches_per_step": int(n),
-                           "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
-                           "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)}
+        out["roofline"] = wl.conv_roofline(a.dtype)
+        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = _pmc_traffic(a.version, H, W, a.interval, a.dtype, B)
+
+    # ---- secondary measurements, same harness (single GPU, headline configuration only) ----------------------------------
+    if rank == 0 and world == 1 and dist is None and a.secondary == "auto" and headline_cfg:
+        sec = {}
+        steps2, warm2 = max(2, a.steps // 2), 1
+
+        def rate(w, el, steps):
+            return round(steps * a.interval * w.B / el, 2)
+        try:
+            el = wl.timed_pcie(steps2, warm2)
+            sec["accel18_batch%d_pcie_inclusive" % B] = {
+                "value": rate(wl, el, steps2), "unit": "frames/s",
+                "what": "same %d clips per call; per frame: image from page-locked host memory (next frame's upload overlaps the "
+                        "running forward), forward, uint8 label map back on the host" % B}
+        except Exception as e:
+            sec["accel18_batch%d_pcie_inclusive" % B] = {"error": repr(e)}
+        wl.close()
+        for name, version, b in (("accel18_batch1", "18", 1), ("accel101_batch%d" % B, "101", B)):
+            try:
+                w2 = Workload(version, b, H, W, a.interval, local_rank, rank, config)
+                el = w2.timed(steps2 * (4 if b == 1 else 1), warm2)
+                rf = w2.conv_roofline(a.dtype)
+                sec[name] = {"value": rate(w2, el, steps2 * (4 if b == 1 else 1)), "unit": "frames/s", "clips_per_call": b,
+                             "what": "Accel-%s, %d clip(s) per call, resident in HBM (the headline's definition)%s"
+                                     % (version, b, "; the reference's TEST.BATCH_IMAGES: 1" if b == 1 else ""),
+                             "conv_tflops": rf["achieved"], "conv_frac_of_peak": rf["frac"]}
+                if b == 1:
+                    el = w2.timed_pcie(steps2 * 4, warm2)
+                    v = rate(w2, el, steps2 * 4)
+                    sec["accel18_batch1_pcie_inclusive"] = {
+                        "value": v, "unit": "frames/s",
+                        "what": "the reference's timing definition (demo.py:234-250) at its own batch: host frame in, forward, label "
+                                "map on the host, per frame; page-locked frames, next upload overlapped"}
+                    out["vs_baseline"] = round(v / K80_ACCEL18_FPS, 2)
+                w2.close()
+            except Exception as e:
+                sec[name] = {"error": repr(e)}
+        out["secondary"] = sec
+    else:
+        wl.close()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.version, a.interval)
+
     def finish():
         if dist is not None:
             with _StdoutToStderr():
