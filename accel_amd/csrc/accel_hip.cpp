@@ -540,6 +540,25 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.force_tile = (int)kv_int(kv, "tile", -1);
     if (c.force_tile >= 0 && !conv_tile_valid(c.force_tile))
         return fail(ACCEL_ERR_ARG, "conv %s: launch geometry id %d is not part of this build", op.name.c_str(), c.force_tile);
+    {
+        // Winograd F(2x2,3x3) form of the layer (3x3 / stride 1 / dilation 1 / pad 1): weights transformed here, in
+        // double, once; offered to the autotuner beside the direct tiles (ACCEL_WINOGRAD=0 withholds it)
+        const char* we = getenv("ACCEL_WINOGRAD");
+        const bool want = !(we && we[0] == '0') || c.force_tile == CONV_TILE_WINO;
+        c.M = op.a.N * c.Ho * c.Wo;
+        if (want && !cols && cin == cin_pad && conv_wino_eligible(c)) {
+            c.wino_rows = conv_wino_rows(cout_store);
+            std::vector<float> wu((size_t)(cin_pad / 8) * 16 * c.wino_rows * 8, 0.f);
+            conv_wino_pack(w->data.data(), cout, cin, cin_pad, c.wino_rows, wu.data());
+            void* du = nullptr;
+            if ((rc = dev_upload(p, wu.data(), wu.size() * sizeof(float), &du))) return rc;
+            c.wu = static_cast<const float*>(du);
+            c.wu_bytes = (unsigned)(wu.size() * sizeof(float));
+        } else if (c.force_tile == CONV_TILE_WINO) {
+            return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
+                                       "size and channels in multiples of 8 only", op.name.c_str());
+        }
+    }
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;
@@ -905,6 +924,7 @@ static int autotune_plan(accel_plan* p)
         if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
         else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
+            if (c.wu) cs.push_back({CONV_TILE_WINO, 0, 0});
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
@@ -944,7 +964,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16, c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "kernels.h"
+#include "conv_common.h"
 
 // Diagnostic build only (-DACCEL_CONV_TIMELINE, scripts/microbench/timeline.py): per-block timestamps of the pipelined
 // kernel (entry / first tile in LDS / K loop done / stores retired) on the 100 MHz constant clock.
@@ -41,41 +42,6 @@ extern "C" int accel_debug_conv_timeline(unsigned long long* out, int n)
 #else
 #define CONV_TL(slot) do { } while (0)
 #endif
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer resources: out-of-range offsets return 0 on loads and are dropped on
-// stores, so image borders, ragged tiles and padded K need no branches.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-#define ACCEL_BUF_FLAGS 0x00020000   // gfx9 raw buffer, 32-bit data format
-#define OOB 0xFFFFFFFFu
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, ACCEL_BUF_FLAGS);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off)
-{
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, float v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
-}
-
-// exact k -> (tap, ci) and tap -> (ky, kx) without integer division
-__device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, int& r)
-{
-    q = (int)((float)a * inv_d);
-    r = a - q * d;
-    if (r < 0) { --q; r += d; }
-    else if (r >= d) { ++q; r -= d; }
-}
 
 // Shared tail of both conv kernels: split-K partial store or the fused epilogue
 // (scale/shift -> +residual -> activation -> store, optional dual output).
@@ -931,7 +897,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if (tile >= 20 && tile <= 30) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35);
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO;
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
@@ -952,6 +918,7 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
+    if (tile == CONV_TILE_WINO) return 0;      // the Winograd kernel never splits K
     tile_dims(tile, bm, bn);
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
@@ -975,6 +942,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // 5-9 the same geometries with the software-pipelined schedule (MID = 2);
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
+    if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
     if (p.f16) {      // fp16-MFMA path: geometry ids 0-4 / 10-12 map onto the same tile shapes
         switch (conv_pick_tile(p)) {
             case 0: case 5: return launch_f16<128, 128, 2, 2>(p, st);

@@ -39,12 +39,22 @@ struct ConvParams {
     unsigned x_bytes, y_bytes, y2_bytes, res_bytes;   // extents of the views (buffer-resource bounds)
     unsigned w_bytes;      // bytes of one weight class
     const int4* ktab;      // per K step (and parity class): {dy, dx, input byte offset, 0}; null -> generic path
+    // Winograd F(2x2,3x3) variant (conv_wino.hip, tile id 40): host-transformed weights [C/8][16][wino_rows][8]
+    const float* wu;       // null: the layer has no Winograd form (or ACCEL_WINOGRAD=0)
+    unsigned wu_bytes;
+    int wino_rows;         // output-channel rows of wu (Cout_store rounded up to the block's 64)
+    int wino_T;            // 2x2 output tiles = M / 4, filled by the launcher
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
 int conv_pick_tile(const ConvParams& p);
 int conv_tile_bk(int tile);
 bool conv_tile_valid(int tile);
+#define CONV_TILE_WINO 40
+bool conv_wino_eligible(const ConvParams& p);
+int conv_wino_rows(int cout_store);
+void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, float* out);
+hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
 size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns workspace bytes
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------

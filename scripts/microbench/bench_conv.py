@@ -33,6 +33,15 @@ if __import__('os').environ.get("STEADY"):   # long-K shapes: steady-state main 
         ("K=2304 N=256 M=8192  3x3", 256, 256, 64, 128, 3, 1, 1, 1, 0, "conv"),
         ("K=2304 N=256 M=32768 3x3", 256, 256, 128, 256, 3, 1, 1, 1, 0, "conv"),
     ]
+if __import__('os').environ.get("WINO"):     # the 3x3 / stride-1 layers of the Accel-18 step, at 1 and at 8 clips per call (rows stacked)
+    base = [("res2_2b 3x3 64-64 @256x512", 64, 64, 256, 512, 0), ("r18 s1 3x3 64-64 +res", 64, 64, 256, 512, 1),
+            ("res3_2b 3x3 128-128 @128x256", 128, 128, 128, 256, 0), ("res4_2b 3x3 256-256 @64x128", 256, 256, 64, 128, 0),
+            ("r18 res5 3x3 512-512 @32x64", 512, 512, 32, 64, 0), ("flow conv5_1 3x3 512-512 @16x32", 512, 512, 16, 32, 0),
+            ("flow conv6_1 3x3 1024-1024 @8x16", 1024, 1024, 8, 16, 0)]
+    SHAPES = []
+    for (n, ci, co, h, w, rs) in base:
+        SHAPES.append((n + " x1", ci, co, h, w, 3, 1, 1, 1, rs, "conv"))
+        SHAPES.append((n + " x8", ci, co, 8 * h, w, 3, 1, 1, 1, rs, "conv"))
 if __import__('os').environ.get("KSWEEP"):   # time vs K at fixed M, N: slope = steady-state rate, intercept = fixed cost per launch
     SHAPES = [("K=%d N=256 M=8192" % k, k, 256, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 64, 128, 256, 512, 1024, 2304, 4608, 8192)]
     SHAPES += [("K=%d N=1024 M=8192" % k, k, 1024, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 256, 1024, 4096)]

@@ -261,3 +261,54 @@ def test_conv2d_fuzz(ctx, case):
         tile = -1
     got = ctx.conv2d(x, w, b, s, pad, d, residual=res, act=act, tile=tile)
     close(got, ref)
+
+
+# ---- Winograd F(2x2,3x3) kernel (launch geometry id 40, conv_wino.hip): 3x3 / stride 1 / dilation 1 / pad 1 ----------
+WINO_CASES = [
+    # N, C, K, H, W
+    (1, 64, 64, 16, 32),        # exactly one tile block / one channel block
+    (1, 256, 256, 8, 16),       # res4 branch2b shape (small image), 4 channel blocks, long K loop
+    (1, 128, 200, 20, 36),      # ragged channel block (200 = 3 x 64 + 8), ragged tile block (180 tiles)
+    (3, 64, 72, 10, 14),        # batch: tile blocks straddle images; 72 channels
+    (1, 16, 40, 6, 6),          # shortest K loop (2 steps), 9 tiles
+    (2, 512, 64, 4, 8),         # deep K, low resolution
+    (1, 64, 18, 12, 20),        # 18-channel offset conv shape
+]
+
+
+@pytest.mark.parametrize("N,C,K,H,W", WINO_CASES)
+def test_conv2d_winograd_matches_oracle(ctx, N, C, K, H, W):
+    x, w, b = rnd(50, N, C, H, W), rnd(51, K, C, 3, 3, scale=(2.0 / (C * 9)) ** 0.5), rnd(52, K)
+    ref = O.conv2d(x, w, b, 1, 1, 1)
+    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=40), ref)
+    # and against the direct kernel on the same inputs: two evaluations of one function on this GPU
+    direct = ctx.conv2d(x, w, b, 1, 1, 1, tile=3)
+    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=40), direct, 2e-5)
+
+
+def test_conv2d_winograd_fused_epilogue_and_borders(ctx):
+    C, K, H, W = 64, 96, 20, 28
+    x, w = rnd(60, 1, C, H, W), rnd(61, K, C, 3, 3, scale=0.05)
+    scale, shift, res = rnd(62, K), rnd(63, K), rnd(64, 1, K, H, W)
+    ref = O.conv2d(x, w, None, 1, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=1, tile=40), O.relu(ref))
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=2, slope=0.1, tile=40),
+          O.leaky_relu(ref, 0.1))
+    # an impulse in every corner and on every edge: the zero padding of the 4x4 input patches
+    xi = np.zeros((1, 16, 6, 8), np.float32)
+    for (yy, xx) in ((0, 0), (0, 7), (5, 0), (5, 7), (0, 3), (5, 4), (2, 0), (3, 7)):
+        xi[0, :, yy, xx] = rnd(65 + yy + xx, 16)
+    wi = rnd(66, 32, 16, 3, 3)
+    np.testing.assert_allclose(ctx.conv2d(xi, wi, None, 1, 1, 1, tile=40), O.conv2d(xi, wi, None, 1, 1, 1), rtol=0, atol=2e-5)
+
+
+def test_conv2d_winograd_rejects_other_geometries(ctx):
+    from accel_amd.runtime import AccelError
+    x, w = rnd(70, 1, 64, 8, 8), rnd(71, 64, 64, 3, 3)
+    for (s, p, d) in ((2, 1, 1), (1, 2, 2), (1, 0, 1)):
+        with pytest.raises(AccelError, match="Winograd"):
+            ctx.conv2d(x, w, None, s, p, d, tile=40)
+    with pytest.raises(AccelError, match="Winograd"):
+        ctx.conv2d(rnd(72, 1, 64, 7, 9), w, None, 1, 1, 1, tile=40)       # odd output size
+    with pytest.raises(AccelError, match="not part of this build"):
+        ctx.conv2d(x, w, None, 1, 1, 1, tile=21)                          # timing-only ablation id: diagnostics build only
