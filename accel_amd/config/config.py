@@ -46,7 +46,7 @@ def _defaults():
     c.TRAIN = edict(lr=0, lr_step='', lr_factor=0.1, warmup=False, warmup_lr=0, warmup_step=0, momentum=0.9,
                     wd=0.0005, begin_epoch=0, end_epoch=0, model_prefix='', RESUME=False, FLIP=True,
                     SHUFFLE=True, ENABLE_OHEM=False, BATCH_IMAGES=1, END2END=False, ASPECT_GROUPING=True,
-                    MIN_OFFSET=-4, MAX_OFFSET=0)
+                    MIN_OFFSET=-4, MAX_OFFSET=0, KEY_INTERVAL=5)
     c.TEST = edict(BATCH_IMAGES=1, KEY_FRAME_INTERVAL=5, max_per_image=300, test_epoch=0)
     return c
 

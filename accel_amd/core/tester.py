@@ -90,6 +90,13 @@ class Predictor(object):
         if max_data_shapes:
             for k, v in max_data_shapes[0]:
                 shapes.setdefault(k, v)
+        if provide_label and provide_label[0]:
+            for k, v in provide_label[0]:
+                shapes.setdefault(k, v)
+        # inputs beyond data / data_key / feat_key (the training graphs: data_ref, eq_flag, label) bind at the given shapes
+        self._extra_shapes = {k: tuple(v) for k, v in shapes.items()
+                              if k not in ("data", "data_key", "feat_key") and k in symbol.list_arguments()}
+        self._is_train = "data_ref" in symbol.list_arguments()
         if "data" in shapes:
             self._bind(tuple(shapes["data"])[2:], tuple(shapes["data"])[0])
 
@@ -122,6 +129,7 @@ class Predictor(object):
         feat_shape = (N, 2048, 1, 1) if self._is_key else (N, 2048, H // 16, W // 16)
         shapes = {"data": (N, 3, H, W), "data_key": (N, 3, H, W), "feat_key": feat_shape}
         shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}
+        shapes.update(self._extra_shapes)
         self._check_params(self._symbol, shapes)
         model = self._explicit_model
         token = params_token(self._arg_params, self._aux_params)
@@ -147,7 +155,7 @@ class Predictor(object):
         for name, d in lw.derived_bufs.items():      # rebuild plans of the derived persistent buffers (featG = fc6_weight * feat)
             if not self._is_key and ("init:" + name) not in model.plans:
                 model.add_plan("init:" + name, _lower.init_plan_text(name, d)).finalize()
-        role = "key" if self._is_key else "cur"      # the roles accel_key_forward / accel_cur_forward look up
+        role = "train" if self._is_train else "key" if self._is_key else "cur"      # key / cur: what accel_key_forward / accel_cur_forward look up
         if role in model.plans:
             role = "%s_%x" % (role, id(self) & 0xFFFFFF)
         plan = model.add_plan(role, text)
@@ -186,6 +194,9 @@ class Predictor(object):
                 m.write("data", _host(arrays["data"]))
             res["data"] = tag
         pre.pop("data", None)
+        for name in self._data_names:          # further image inputs (data_ref of the training graphs)
+            if name not in ("data", "data_key", "feat_key") and name in lw.image_vars:
+                m.write(name, _host(arrays[name]))
         if not self._is_key:
             fk = arrays["feat_key"]
             ref = getattr(fk, "device_ref", None)

@@ -55,8 +55,17 @@ class VBuf(object):
 
 
 class View(object):
-    def __init__(self, buf, C, coff=0):
-        self.buf, self.C, self.coff = buf, C, coff
+    """Channel slice [coff, coff + C) of images [img0, img0 + nimg) of a physical buffer (images are stacked pixel-major,
+    so a batch slice is a contiguous sub-range)."""
+
+    def __init__(self, buf, C, coff=0, img0=0, nimg=None):
+        self.buf, self.C, self.coff, self.img0 = buf, C, coff, img0
+        self.nimg = buf.N if nimg is None else nimg
+
+    def image(self, i0, n):
+        """images [i0, i0 + n) of this view (mx.sym.split along the batch axis)"""
+        assert 0 <= i0 and i0 + n <= self.nimg
+        return View(self.buf, self.C, self.coff, self.img0 + i0, n)
 
     @property
     def H(self):
@@ -67,9 +76,9 @@ class View(object):
         return self.buf.W
 
     def ref(self):
-        r = "%s:%d:%d:%d:%d:%d" % (self.buf.space, self.buf.off + self.coff * 4, self.C,
-                                   self.buf.Cs, self.buf.H, self.buf.W)
-        return r if self.buf.N == 1 else r + ":%d" % self.buf.N     # batch: images stacked pixel-major
+        off = self.buf.off + self.coff * 4 + self.img0 * self.buf.H * self.buf.W * self.buf.Cs * 4
+        r = "%s:%d:%d:%d:%d:%d" % (self.buf.space, off, self.C, self.buf.Cs, self.buf.H, self.buf.W)
+        return r if self.nimg == 1 else r + ":%d" % self.nimg     # batch: images stacked pixel-major
 
 
 class Lowering(object):
@@ -102,7 +111,7 @@ class Lowering(object):
         self.deps = {}
         for n in self.nodes:
             if n.op == "null":
-                self.deps[id(n)] = frozenset([n.name]) if n.name in ("data", "data_key", "feat_key") else frozenset()
+                self.deps[id(n)] = frozenset([n.name]) if n.name in ("data", "data_key", "feat_key", "data_ref") else frozenset()
             else:
                 d = frozenset()
                 for idx, i in enumerate(n.inputs):
@@ -118,8 +127,15 @@ class Lowering(object):
         data_shape = input_shapes["data"]
         self.N, self.H, self.W = int(data_shape[0]), int(data_shape[2]), int(data_shape[3])
         self.nsfx = "" if self.N == 1 else ":%d" % self.N     # batch suffix of literal buffer references
+        # image inputs (N x 3 x H x W variables): `data`, `data_key` of the test graphs, `data_ref` of the training graphs
+        self.image_vars = {}
+        for n in self.nodes:
+            if n.op == "null" and n.name in input_shapes and len(input_shapes[n.name]) == 4 and int(input_shapes[n.name][1]) == 3:
+                self.image_vars[n.name] = int(input_shapes[n.name][0])
         for name in ("data", "data_key"):
-            self.pbufs[name] = self.N * 3 * self.H * self.W * 4
+            self.image_vars.setdefault(name, self.N)
+        for name, nimg in self.image_vars.items():
+            self.pbufs[name] = nimg * 3 * self.H * self.W * 4
 
     # ---- helpers ---------------------------------------------------------------
     def shape(self, n):
@@ -128,15 +144,16 @@ class Lowering(object):
     def consumers(self, n):
         return self.cons.get(id(n), [])
 
-    def new_buf(self, C, H, W, Cs=None):
-        b = VBuf(len(self.bufs), Cs or _r4(C), H, W, N=self.N)
+    def new_buf(self, C, H, W, Cs=None, N=None):
+        b = VBuf(len(self.bufs), Cs or _r4(C), H, W, N=self.N if N is None else N)
         self.bufs.append(b)
         return b
 
-    def pbuf_view(self, name, C, H, W, Cs=None):
+    def pbuf_view(self, name, C, H, W, Cs=None, N=None):
         Cs = Cs or _r4(C)
-        b = VBuf(-1, Cs, H, W, space=name, N=self.N)
-        self.pbufs[name] = max(self.pbufs.get(name, 0), self.N * H * W * Cs * 4)
+        N = self.N if N is None else N
+        b = VBuf(-1, Cs, H, W, space=name, N=N)
+        self.pbufs[name] = max(self.pbufs.get(name, 0), N * H * W * Cs * 4)
         return View(b, C)
 
     def _head_on_feature(self, conv, feature):
@@ -165,16 +182,16 @@ class Lowering(object):
         """Where the value of `node` must be written."""
         if id(node) in self.concat_slot:
             return self.concat_slot[id(node)]
-        _, C, H, W = self.shape(node)
+        N, C, H, W = self.shape(node)
         if id(node) in self.head_ids and node.name == "res5c_relu":
-            return self.pbuf_view("feat", C, H, W)
-        return View(self.new_buf(C, H, W), C)
+            return self.pbuf_view("feat", C, H, W, N=N)
+        return View(self.new_buf(C, H, W, N=N), C)
 
     @staticmethod
     def _bkey(v):
         return ("A", v.buf.id) if v.buf.space == "A" else ("P", v.buf.space)
 
-    def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0, nbytes_fixed=0.0):
+    def emit(self, kind, args, reads, writes, flops=0.0, nbytes=0.0, nbytes_fixed=0.0, n=None):
         idx = len(self.ops)
         for v in list(reads) + list(writes):
             if v is not None and v.buf.space == "A":
@@ -198,7 +215,8 @@ class Lowering(object):
             args["stream"] = st
             if waits:
                 args["wait"] = ",".join(str(w) for w in sorted(waits))
-        flops, nbytes = flops * self.N, nbytes * self.N + nbytes_fixed     # callers give per-image work (+ weights, read once)
+        n = self.N if n is None else n
+        flops, nbytes = flops * n, nbytes * n + nbytes_fixed     # callers give per-image work (+ weights, read once)
         if flops:
             args["flops"] = "%.6g" % flops
             self.total_flops += flops
@@ -209,15 +227,15 @@ class Lowering(object):
     # ---- pre-pass: give Concat inputs their slices ---------------------------------
     def plan_concats(self):
         for n in self.nodes:
-            if n.op != "Concat":
+            if n.op != "Concat" or n.attrs.get("dim", 1) != 1:
                 continue
             if all(i.op == "_div_scalar" for i in n.inputs):
                 continue    # FlowNet input concat -> prep_flow
             if all(i.op == "Crop" and i.inputs[0].op == "Deconvolution" and
                    i.inputs[0].attrs["kernel"] == (32, 32) for i in n.inputs):
                 continue    # score concat -> score_tail
-            _, C, H, W = self.shape(n)
-            buf = self.new_buf(C, H, W)
+            N, C, H, W = self.shape(n)
+            buf = self.new_buf(C, H, W, N=N)
             off = 0
             for k, i in enumerate(n.inputs):
                 ci = self.shape(i)[1]
@@ -231,27 +249,69 @@ class Lowering(object):
             self.absorbed.add(id(n))
 
     # ---- image entry points ------------------------------------------------------------
-    def image_nhwc4(self, var, bn=None):
-        key = ("img", var.name, bn.name if bn is not None else None)
+    def image_sources(self, node):
+        """`node` as a list of input images [(variable name, image index)], or None: an image variable, a batch slice
+        of one (mx.sym.split axis 0) or a batch concatenation of those (mx.sym.Concat dim 0) -- how the training graphs
+        assemble their FlowNet / ResNet inputs from `data` and `data_ref` (accel_18.py:43-48, accel_101.py:43-57)."""
+        if node.op == "null":
+            return [(node.name, i) for i in range(self.image_vars[node.name])] if node.name in self.image_vars else None
+        if node.op == "_split_out":
+            src = self.image_sources(node.inputs[0])
+            if src is None:
+                return None
+            per = len(src) // node.attrs["num_outputs"]
+            return src[node.attrs["index"] * per:(node.attrs["index"] + 1) * per]
+        if node.op == "Concat" and node.attrs.get("dim", 1) == 0:
+            parts = [self.image_sources(i) for i in node.inputs]
+            return None if any(q is None for q in parts) else [x for q in parts for x in q]
+        return None
+
+    @staticmethod
+    def _runs(src):
+        """[(var, first index, count, position in the list)] for maximal runs of consecutive images of one variable"""
+        runs, i = [], 0
+        while i < len(src):
+            j = i
+            while j + 1 < len(src) and src[j + 1] == (src[j][0], src[j][1] + 1):
+                j += 1
+            runs.append((src[i][0], src[i][1], j - i + 1, i))
+            i = j + 1
+        return runs
+
+    def _img_ref(self, var, i0, n):
+        r = "%s:%d:3:4:%d:%d" % (var, i0 * 3 * self.H * self.W * 4, self.H, self.W)
+        return r if n == 1 else r + ":%d" % n
+
+    def image_nhwc4(self, node, bn=None):
+        src = self.image_sources(node)
+        key = ("img", tuple(src), bn.name if bn is not None else None)
         if key in self.val:
             return self.val[key]
-        v = View(self.new_buf(3, self.H, self.W), 3)
-        args = {"src": "%s:0:3:4:%d:%d%s" % (var.name, self.H, self.W, self.nsfx), "dst": v, "H": self.H, "W": self.W}
-        if bn is not None:
-            args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
-        self.emit("prep_rgb", args, [], [v], nbytes=(12 + 16) * self.H * self.W)
+        v = View(self.new_buf(3, self.H, self.W, N=len(src)), 3)
+        for var, i0, n, pos in self._runs(src):
+            dst = v.image(pos, n)
+            args = {"src": self._img_ref(var, i0, n), "dst": dst, "H": self.H, "W": self.W}
+            if bn is not None:
+                args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
+            self.emit("prep_rgb", args, [], [dst], nbytes=(12 + 16) * self.H * self.W, n=n)
         self.val[key] = v
+        for n_ in (node,):
+            self.absorbed.add(id(n_))
         return v
 
     def input_view(self, node):
         """View holding the value of `node` as a conv/pool input."""
+        if self.image_sources(node) is not None:
+            return self.image_nhwc4(node)
         if node.op == "null":
-            if node.name in ("data", "data_key"):
-                return self.image_nhwc4(node)
             if node.name == "feat_key":
-                _, C, H, W = self.shape(node)
-                return self.pbuf_view("feat", C, H, W)
+                N, C, H, W = self.shape(node)
+                return self.pbuf_view("feat", C, H, W, N=N)
             raise NotImplementedError("variable %s used as activation" % node.name)
+        if node.op == "_split_out":       # batch slice of an activation (accel_101.py:47-49)
+            parent = self.input_view(node.inputs[0])
+            per = parent.nimg // node.attrs["num_outputs"]
+            return parent.image(node.attrs["index"] * per, per)
         if id(node) not in self.val:
             raise NotImplementedError("value of %s (%s) was not materialised before use" % (node.name, node.op))
         return self.val[id(node)]
@@ -269,7 +329,7 @@ class Lowering(object):
         if op == "Convolution" and a["num_group"] != 1:
             raise NotImplementedError("grouped Convolution %s" % A.name)
         # BatchNorm on the raw image (bn_data) folds into the image converter
-        if x.op == "BatchNorm" and x.inputs[0].op == "null" and x.inputs[0].name in ("data", "data_key"):
+        if x.op == "BatchNorm" and self.image_sources(x.inputs[0]) is not None:
             xin = self.image_nhwc4(x.inputs[0], bn=x)
             self.absorbed.add(id(x))
         elif op == "DeformableConvolution":
@@ -363,7 +423,7 @@ class Lowering(object):
                         break
 
         _, cin, hi, wi = self.shape(x)
-        _, cout, ho, wo = self.shape(cur)
+        nb, cout, ho, wo = self.shape(cur)
         args = {"name": opname, "out": out, "w": wname, "act": act, "slope": slope, "cin": cin, "cout": cout, "mode": mode}
         bias2 = None
         if feat_image is not None:
@@ -375,11 +435,11 @@ class Lowering(object):
             xv, offv = self.input_view(x), self.input_view(off)
             kh, kw = a["kernel"]
             cp = _r4(cin)
-            cols = View(self.new_buf(kh * kw * cp, ho, wo), kh * kw * cp)
+            cols = View(self.new_buf(kh * kw * cp, ho, wo, N=nb), kh * kw * cp)
             self.emit("dcn_cols", {"name": A.name + "_cols", "in": xv, "off": offv, "out": cols,
                                    "k": "%d,%d" % a["kernel"], "s": "%d,%d" % a["stride"], "p": "%d,%d" % a["pad"],
                                    "d": "%d,%d" % a["dilate"], "dg": a["num_deformable_group"]},
-                      [xv, offv], [cols], nbytes=4.0 * ho * wo * kh * kw * cp * 2)
+                      [xv, offv], [cols], nbytes=4.0 * ho * wo * kh * kw * cp * 2, n=nb)
             args.update({"in": cols, "mode": "cols", "wk": "%d,%d" % a["kernel"], "k": "1,1"})
             reads.append(cols)
             flops = 2.0 * ho * wo * cout * cin * kh * kw
@@ -412,7 +472,7 @@ class Lowering(object):
         in_elems = ho * wo * kk * _r4(cin) if op == "DeformableConvolution" else hi * wi * cin
         w_elems = cout * cin * (16 if mode == "deconv2x" else kk)
         nbytes = 4.0 * (in_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
-        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes, nbytes_fixed=4.0 * w_elems)
+        self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes, nbytes_fixed=4.0 * w_elems, n=nb)
         self.absorbed.add(id(A))
         if feat_image is not None:
             out, out2 = out2, None     # the graph value of the chain is the biased, activated copy
@@ -461,9 +521,9 @@ class Lowering(object):
                 "s": "%d,%d" % a["stride"], "p": "%d,%d" % a["pad"], "act": relu}
         if bn is not None:
             args.update({"bn": bn.name, "eps": bn.attrs["eps"], "fixg": int(bn.attrs["fix_gamma"])})
-        _, c, ho, wo = self.shape(P)
+        nb, c, ho, wo = self.shape(P)
         _, _, hi, wi = self.shape(x)
-        self.emit("pool", args, [xin], [out], nbytes=4.0 * c * (hi * wi + ho * wo))
+        self.emit("pool", args, [xin], [out], nbytes=4.0 * c * (hi * wi + ho * wo), n=nb)
         for n in [P] + chain:
             self.absorbed.add(id(n))
             self.val[id(n)] = out
@@ -475,16 +535,29 @@ class Lowering(object):
             raise NotImplementedError("FlowNet input pooling must be avg 2x2/2")
         srcs = []
         for d in cat.inputs:
-            if abs(d.attrs["scalar"] - 255.0) > 0 or d.inputs[0].op != "null":
+            if abs(d.attrs["scalar"] - 255.0) > 0 or self.image_sources(d.inputs[0]) is None:
                 raise NotImplementedError("FlowNet input must be image / 255.0")
-            srcs.append(d.inputs[0].name)
+            srcs.append(self.image_sources(d.inputs[0]))
             self.absorbed.add(id(d))
+            self.absorbed.add(id(d.inputs[0]))
         self.absorbed.add(id(cat))
-        out = View(self.new_buf(6, self.H // 2, self.W // 2, Cs=8), 6)
-        self.emit("prep_flow", {"cur": "%s:0:3:4:%d:%d%s" % (srcs[0], self.H, self.W, self.nsfx),
-                                "prev": "%s:0:3:4:%d:%d%s" % (srcs[1], self.H, self.W, self.nsfx),
-                                "dst": out, "H": self.H, "W": self.W}, [], [out],
-                  nbytes=24.0 * self.H * self.W + 8.0 * self.H * self.W)
+        cur, prev = srcs
+        if len(cur) != len(prev):
+            raise NotImplementedError("FlowNet input: %d current vs %d reference images" % (len(cur), len(prev)))
+        nb = len(cur)
+        out = View(self.new_buf(6, self.H // 2, self.W // 2, Cs=8, N=nb), 6)
+        # one launch per run of image pairs that is contiguous in both sources (the test graphs: one launch)
+        i = 0
+        while i < nb:
+            j = i
+            while j + 1 < nb and cur[j + 1] == (cur[j][0], cur[j][1] + 1) and prev[j + 1] == (prev[j][0], prev[j][1] + 1):
+                j += 1
+            n = j - i + 1
+            dst = out.image(i, n)
+            self.emit("prep_flow", {"cur": self._img_ref(cur[i][0], cur[i][1], n), "prev": self._img_ref(prev[i][0], prev[i][1], n),
+                                    "dst": dst, "H": self.H, "W": self.W}, [], [dst],
+                      nbytes=24.0 * self.H * self.W + 8.0 * self.H * self.W, n=n)
+            i = j + 1
         self.absorbed.add(id(P))
         self.val[id(P)] = out
 
@@ -496,21 +569,30 @@ class Lowering(object):
             grid = B
         else:
             feat, grid = B.inputs
+            sl = None
+            if grid.op == "_split_out":          # training graphs: one grid per intermediate frame (accel_18.py:53-57)
+                sl, grid = grid, grid.inputs[0]
             if grid.op != "GridGenerator":
                 raise NotImplementedError("BilinearSampler grid must come from GridGenerator(warp)")
             flow_node = grid.inputs[0]
         flow = self.input_view(flow_node)
+        if B.op != "Custom" and sl is not None:
+            per = flow.nimg // sl.attrs["num_outputs"]
+            flow = flow.image(sl.attrs["index"] * per, per)
+            self.absorbed.add(id(sl))
         fin = self.input_view(feat)
         out = self.dest_for(B)
-        _, C, H, W = self.shape(B)
+        nb, C, H, W = self.shape(B)
+        if flow.nimg != fin.nimg:
+            raise NotImplementedError("warp %s: %d feature images vs %d flow fields" % (B.name, fin.nimg, flow.nimg))
         self.emit("warp", {"name": B.name, "feat": fin, "flow": flow, "out": out}, [fin, flow], [out],
-                  nbytes=2.0 * 4 * C * H * W + 8.0 * H * W)
+                  nbytes=2.0 * 4 * C * H * W + 8.0 * H * W, n=nb)
         self.absorbed.update((id(B), id(grid)))
         self.val[id(B)] = out
         if id(B) in self.head_ids:
             # the propagated feature: becomes `feat` for the next frame (demo.py:241-243)
-            dst = self.pbuf_view("feat", C, H, W)
-            self.emit("copy", {"src": out, "dst": dst}, [out], [dst], nbytes=8.0 * C * H * W)
+            dst = self.pbuf_view("feat", C, H, W, N=nb)
+            self.emit("copy", {"src": out, "dst": dst}, [out], [dst], nbytes=8.0 * C * H * W, n=nb)
             self.outputs[B.name + "_output"] = dst
         # Warp and a 1x1 convolution commute (both linear, the bilinear weights do not depend on the channel):
         #   relu(W * warp(F) + b) = relu(warp(W * F) + b),
@@ -556,14 +638,16 @@ class Lowering(object):
         if any(u is None for u in ups):
             raise NotImplementedError("unsupported score tail at %s" % node.name)
         ncls = ups[0].attrs["num_filter"]
-        logits = self.pbuf_view("logits", ncls, self.H, self.W, Cs=4)
-        self.pbufs["logits"] = self.N * ncls * self.H * self.W * 4
-        labels = self.pbuf_view("labels", 1, self.H, self.W, Cs=4)
-        self.pbufs["labels"] = (self.N * self.H * self.W + 255) // 256 * 256
+        nb = self.shape(ups[0])[0]
+        sfx = "" if nb == 1 else ":%d" % nb
+        logits = self.pbuf_view("logits", ncls, self.H, self.W, Cs=4, N=nb)
+        self.pbufs["logits"] = nb * ncls * self.H * self.W * 4
+        labels = self.pbuf_view("labels", 1, self.H, self.W, Cs=4, N=nb)
+        self.pbufs["labels"] = (nb * self.H * self.W + 255) // 256 * 256
         left = self.input_view(ups[0].inputs[0])
         args = {"name": node.name, "left": left, "wl": ups[0].inputs[1].name, "H": self.H, "W": self.W, "ncls": ncls,
-                "logits": "logits:0:%d:4:%d:%d%s" % (ncls, self.H, self.W, self.nsfx),
-                "labels": "labels:0:1:4:%d:%d%s" % (self.H, self.W, self.nsfx)}
+                "logits": "logits:0:%d:4:%d:%d%s" % (ncls, self.H, self.W, sfx),
+                "labels": "labels:0:1:4:%d:%d%s" % (self.H, self.W, sfx)}
         reads = [left]
         flops = 0.0
         if corr is not None:
@@ -573,7 +657,7 @@ class Lowering(object):
             flops = 2.0 * ncls * 2 * ncls * self.H * self.W
         if softmax is not None:
             args["softmax"] = 1      # SoftmaxOutput(multi_output=True) at test time: softmax over the class axis
-        self.emit("score_tail", args, reads, [], flops=flops, nbytes=4.0 * ncls * self.H * self.W + self.H * self.W)
+        self.emit("score_tail", args, reads, [], flops=flops, nbytes=4.0 * ncls * self.H * self.W + self.H * self.W, n=nb)
         for n in [node] + list(crops) + ups + ([corr] if corr is not None else []) + ([softmax] if softmax is not None else []):
             self.absorbed.add(id(n))
         self.outputs[(softmax or node).name + "_output"] = "logits"
@@ -597,11 +681,26 @@ class Lowering(object):
                     self.lower_tail(n, [n], softmax=cons[0])
                 continue
             if op == "Concat":
-                continue   # score concat; handled at the correction conv
-            if op == "Convolution" and n.inputs[0].op == "Concat" and id(n.inputs[0]) not in self.val:
+                continue   # score concat: handled at the correction conv; batch concat of images: at its consumer
+            if op == "_split_out":
+                # a view of its input, resolved where it is consumed -- except as a member of a channel Concat, whose
+                # buffer nobody else fills (accel_101.py:48-49,66: the current frame's half of the ResNet batch)
+                if id(n) in self.concat_slot and self.image_sources(n) is None:
+                    src, dst = self.input_view(n), self.concat_slot[id(n)]
+                    nb, C, H, W = self.shape(n)
+                    self.emit("copy", {"src": src, "dst": dst}, [src], [dst], nbytes=8.0 * C * H * W, n=nb)
+                    self.val[id(n)] = dst
+                continue
+            if op == "SoftmaxOutput" and id(n) in self.absorbed:
+                continue
+            if op == "Convolution" and n.inputs[0].op == "Concat" and n.inputs[0].attrs.get("dim", 1) == 1 \
+                    and id(n.inputs[0]) not in self.val:
                 cat = n.inputs[0]
                 if a_is_1x1(n) and len(cat.inputs) == 2:
-                    self.lower_tail(n, cat.inputs, corr=n)
+                    cons = self.consumers(n)
+                    sm = cons[0] if (len(cons) == 1 and cons[0].op == "SoftmaxOutput" and id(cons[0]) in self.head_ids
+                                     and cons[0].attrs.get("multi_output") and id(n) not in self.head_ids) else None
+                    self.lower_tail(n, cat.inputs, corr=n, softmax=sm)
                     self.absorbed.add(id(cat))
                     continue
                 raise NotImplementedError("Convolution %s over an unsupported Concat" % n.name)

@@ -14,6 +14,7 @@ contrib = _types.SimpleNamespace(
     symbol=_types.SimpleNamespace(DeformableConvolution=symbol.DeformableConvolution),
     sym=_types.SimpleNamespace(DeformableConvolution=symbol.DeformableConvolution))
 io = _types.SimpleNamespace(DataBatch=DataBatch)
+sym.split = symbol.split
 nd = _types.SimpleNamespace(array=array, argmax=argmax, zeros=zeros, NDArray=DeviceArray)
 ndarray = nd
 

@@ -185,11 +185,29 @@ def Pooling(data=None, kernel=None, stride=None, pad=None, pool_type="max",
 
 
 def Concat(*data, **kw):
+    """dim=1: channel concatenation; dim=0: batch concatenation (the training graphs stack frames: accel_18.py:47-48)"""
     name = kw.get("name") or _auto_name("concat")
-    dim = kw.get("dim", 1)
-    if dim != 1:
+    dim = int(kw.get("dim", 1))
+    if dim not in (0, 1):
         raise NotImplementedError("Concat(dim=%r)" % (dim,))
-    return Symbol("Concat", name, list(data), {"dim": 1})
+    return Symbol("Concat", name, list(data), {"dim": dim})
+
+
+class _SplitOutputs(list):
+    """mx.sym.split(...) result: indexable, one Symbol per slice (accel_18.py:43,54)."""
+
+
+def split(data=None, num_outputs=None, axis=1, squeeze_axis=False, name=None, **_):
+    """SliceChannel: `num_outputs` equal slices along `axis` (only the batch axis occurs on the Accel path)."""
+    if axis != 0 or squeeze_axis:
+        raise NotImplementedError("split(axis=%r, squeeze_axis=%r)" % (axis, squeeze_axis))
+    name = name or _auto_name("split")
+    n = int(num_outputs)
+    return _SplitOutputs(Symbol("_split_out", "%s_output%d" % (name, i) if n > 1 else name, [data],
+                                {"index": i, "num_outputs": n, "axis": 0}) for i in range(n))
+
+
+SliceChannel = split
 
 
 def Crop(*data, **kw):
@@ -311,12 +329,23 @@ def infer_shapes(sym, known):
             full = a["pooling_convention"] == "full"
             sh[id(s)] = (n, c, _pool_out(h, a["kernel"][0], a["stride"][0], a["pad"][0], full),
                          _pool_out(w, a["kernel"][1], a["stride"][1], a["pad"][1], full))
+        elif op == "Concat" and a["dim"] == 0:
+            shps = [need(i) for i in s.inputs]
+            for t in shps[1:]:
+                if t[1:] != shps[0][1:]:
+                    raise ValueError("Concat %s (dim 0): incompatible shapes %s" % (s.name, shps))
+            sh[id(s)] = (sum(t[0] for t in shps),) + shps[0][1:]
         elif op == "Concat":
             shps = [need(i) for i in s.inputs]
             for t in shps[1:]:
                 if t[0] != shps[0][0] or t[2:] != shps[0][2:]:
                     raise ValueError("Concat %s: incompatible shapes %s" % (s.name, shps))
             sh[id(s)] = (shps[0][0], sum(t[1] for t in shps)) + shps[0][2:]
+        elif op == "_split_out":
+            src = need(s.inputs[0])
+            if src[0] % a["num_outputs"]:
+                raise ValueError("split %s: batch %d is not divisible by %d" % (s.name, src[0], a["num_outputs"]))
+            sh[id(s)] = (src[0] // a["num_outputs"],) + src[1:]
         elif op == "Crop":
             src = need(s.inputs[0])
             if a["num_args"] == 2:

@@ -228,6 +228,43 @@ def cur_forward(P, version, data, data_key, feat_key):
     return out
 
 
+def train_forward(P, version, data, data_ref):
+    """get_train_symbol, forward only: accel_18.py:31-119 (34 / 50 alike), accel_101.py:31-102.
+    data 1x3xHxW (the labelled frame), data_ref (KEY_INTERVAL-1)x3xHxW (key frame, then the intermediate frames).
+    The key frame's feature is warped once per frame pair (ref1<-ref0, ref2<-ref1, .., data<-ref_last; all flows from
+    one FlowNet batch), then corrected by the branch on `data`; SoftmaxOutput(multi_output) = softmax over classes."""
+    version = str(version)
+    n = data_ref.shape[0]
+    hw = data.shape[2:]
+    if version == "101":
+        both = resnet_dcn_101(P, np.concatenate([data_ref[:1], data], axis=0))
+        feat, feat_cur = both[:1], both[1:]
+    else:
+        feat = resnet_dcn_101(P, data_ref[:1])
+    nxt = np.concatenate([data_ref[1:], data], axis=0)
+    flow = flownet(P, nxt, data_ref)
+    for i in range(n):
+        feat = O.flow_warp(feat, flow[i:i + 1])
+    if version == "101":
+        fused = O.conv2d(np.concatenate([feat, feat_cur], axis=1), P["corr_weight"], P["corr_bias"])
+        s = head(P, fused, hw)
+    else:
+        left = head(P, feat, hw)
+        if version in ("18", "34"):
+            p = version + "_"
+            r = resnet_preact_trunk(P, data, p, [2, 2, 2] if version == "18" else [3, 4, 6])
+            r = resnet_dcn_conv5_basic(P, r, p, 2 if version == "18" else 3)
+            r = O.deconv2d(r, P[p + "feat_upsampling_weight"], None, 2, 1)
+            right = head(P, r, hw, p)
+        elif version == "50":
+            right = head(P, resnet_dcn_50(P, data), hw, "curr_")
+        else:
+            raise ValueError(version)
+        s = O.conv2d(np.concatenate([left, right], axis=1), P["corr_weight"], P["corr_bias"])
+    e = np.exp(s - s.max(axis=1, keepdims=True), dtype=np.float32)
+    return {"softmax_output": (e / e.sum(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32), "_logits": s, "_feat": feat}
+
+
 def run_clip(P, version, frames, interval):
     """The demo.py:228-250 schedule on preprocessed frames (list of 1x3xHxW):
     idx % interval == 0 -> key graph, else cur graph with data_key = PREVIOUS

@@ -430,3 +430,44 @@ def test_batched_clips_match_single_clip_runs(demo_cfg, version):
                 np.testing.assert_array_equal(lab[b][safe], np.argmax(ref, axis=0)[safe])
     finally:
         tester.release_models()
+
+
+@pytest.mark.parametrize("version,key_interval", [("18", 5), ("101", 3), ("50", 5)])
+def test_train_symbol_forward(demo_cfg, version, key_interval):
+    """get_train_symbol, forward only (accel_18.py:31-119, accel_101.py:31-102): `data_ref` = key frame + intermediate
+    frames, `data` = the labelled frame; all frame pairs through ONE FlowNet batch, the key feature warped once per pair,
+    then the usual correction; `softmax_output` against the oracle's restatement (probabilities: absolute 1e-4)."""
+    from accel_amd import mx, symbols
+    from accel_amd.core import tester
+    H, W = 128, 256
+    demo_cfg.TRAIN.KEY_INTERVAL = key_interval
+    n_ref = key_interval - 1
+    inst = getattr(getattr(symbols, "accel_" + version), "accel_" + version)()
+    sym = inst.get_train_symbol(demo_cfg)
+    assert sym.list_outputs() == ["softmax_output", "data_ref", "eq_flag"]
+    shapes = {"data": (1, 3, H, W), "data_ref": (n_ref, 3, H, W), "eq_flag": (1,), "label": (1, H, W)}
+    inst.infer_shape(shapes)
+    arg, aux = synth.make_params(inst.arg_shape_dict, inst.aux_shape_dict, data_names=tuple(shapes))
+    frames = _oracle_frames(synth.make_clip(H, W, key_interval), demo_cfg)
+    data, data_ref = frames[-1], np.concatenate(frames[:-1], axis=0)
+    try:
+        pred = tester.Predictor(sym, ["data", "data_ref", "eq_flag"], ["label"], context=[mx.gpu(0)],
+                                provide_data=[[("data", shapes["data"]), ("data_ref", shapes["data_ref"]), ("eq_flag", (1,))]],
+                                provide_label=[[("label", shapes["label"])]], arg_params=arg, aux_params=aux)
+        batch = mx.io.DataBatch(data=[[mx.nd.array(data), mx.nd.array(data_ref), mx.nd.array(np.zeros((1,), np.float32))]], label=[],
+                                provide_data=[[("data", data.shape), ("data_ref", data_ref.shape), ("eq_flag", (1,))]])
+        out = pred.predict(batch)[0]
+        prob = out["softmax_output"].asnumpy()
+        assert out["data_ref"].shape == data_ref.shape
+        lab = mx.nd.argmax(out["softmax_output"], axis=1).asnumpy()
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.train_forward(P, version, data, data_ref)
+    assert prob.shape == (1, 19, H, W)
+    assert float(np.abs(prob - ref["softmax_output"]).max()) <= 1e-4
+    np.testing.assert_allclose(prob.sum(axis=1), 1.0, atol=1e-5)
+    srt = np.sort(ref["softmax_output"], axis=1)
+    safe = ((srt[:, -1] - srt[:, -2]) > 1e-3)[0]
+    np.testing.assert_array_equal(lab[0][safe], np.argmax(ref["softmax_output"], axis=1)[0][safe])

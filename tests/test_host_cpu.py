@@ -483,3 +483,65 @@ def test_params_token_is_content_keyed():
     assert params_token(a) != params_token(b)
     assert params_token(a, {}) == params_token(a) and params_token({"w": a["w"]}) != params_token({"v": a["w"]})
     assert params_token({"w": np.ones((3, 2), np.float32)}) != params_token({"w": np.ones((2, 3), np.float32)})
+
+
+@pytest.mark.parametrize("version,key_interval", [("18", 5), ("34", 5), ("50", 5), ("101", 3)])
+def test_train_symbol_structure_and_lowering(demo_cfg, version, key_interval):
+    """get_train_symbol (accel_18.py:31-119, accel_101.py:31-102): argument / output names, shapes, and a lowering whose
+    kernel list has ONE batched FlowNet pass over KEY_INTERVAL-1 frame pairs and as many chained warps."""
+    from accel_amd import lower, symbols
+    demo_cfg.TRAIN.KEY_INTERVAL = key_interval
+    n = key_interval - 1
+    inst = getattr(getattr(symbols, "accel_" + version), "accel_" + version)()
+    sym = inst.get_train_symbol(demo_cfg)
+    args = sym.list_arguments()
+    assert sym.list_outputs() == ["softmax_output", "data_ref", "eq_flag"]
+    for name in ("data", "data_ref", "eq_flag", "label", "corr_weight", "corr_bias", "fc6_weight", "flow_conv1_weight"):
+        assert name in args, name
+    assert "data_key" not in args and "feat_key" not in args
+    H, W = 128, 256
+    shapes = {"data": (1, 3, H, W), "data_ref": (n, 3, H, W), "eq_flag": (1,), "label": (1, H, W)}
+    inst.infer_shape(shapes)
+    assert inst.arg_shape_dict["corr_weight"] == ((2048, 4096, 1, 1) if version == "101" else (19, 38, 1, 1))
+    _, outs, _ = sym.infer_shape(**shapes)
+    assert outs[0] == (1, 19, H, W) and outs[1] == (n, 3, H, W)
+    text, lw = lower.lower(sym, shapes)
+    lines = text.splitlines()
+    assert sum(l.startswith("warp ") for l in lines) == n
+    flow1 = [l for l in lines if l.startswith("conv ") and "name=flow_conv1 " in l]
+    assert len(flow1) == 1 and (":%d " % n) in flow1[0].replace("out=", " ").replace(" w=", ":X w=") or n == 1     # one batched launch
+    assert sum(l.startswith("prep_flow") for l in lines) <= 2 and "softmax=1" in text
+    assert lw.outputs["softmax_output"] == "logits" and lw.outputs["data_ref"] == "input:data_ref"
+    # ResNet-101 runs once (18/34/50: on the key frame only; 101: key + current frame as one batch of 2)
+    assert sum("name=res5c_branch2c " in l for l in lines) == 1
+
+
+def test_init_weight_rules(demo_cfg):
+    """accel_18.py:321-323, accel_50.py:310-318, accel_101.py:275-289"""
+    from accel_amd.symbols.accel_18 import accel_18
+    from accel_amd.symbols.accel_50 import accel_50
+    from accel_amd.symbols.accel_101 import accel_101
+    H, W = 128, 256
+    for cls, ki in ((accel_18, 5), (accel_50, 5), (accel_101, 3)):
+        demo_cfg.TRAIN.KEY_INTERVAL = ki
+        inst = cls()
+        inst.get_train_symbol(demo_cfg)
+        inst.infer_shape({"data": (1, 3, H, W), "data_ref": (ki - 1, 3, H, W), "eq_flag": (1,), "label": (1, H, W)})
+        arg = {"fc6_weight": np.full((1024, 2048, 1, 1), 2.0, np.float32), "fc6_bias": np.ones(1024, np.float32),
+               "score_weight": np.ones((19, 1024, 1, 1), np.float32), "score_bias": np.ones(19, np.float32),
+               "upsampling_weight": np.ones((19, 1, 32, 32), np.float32)}
+        arg.update({"50_" + k: v * 3 for k, v in list(arg.items())})
+        inst.init_weight(demo_cfg, arg, {}, rng=np.random.default_rng(0))
+        assert arg["corr_bias"].shape == (2048 if cls is accel_101 else 19,) and not arg["corr_bias"].any()
+        w = arg["corr_weight"]
+        if cls is accel_101:
+            # identity on the CURRENT frame's half of the stacked features, zero on the warped half
+            assert w.shape == (2048, 4096, 1, 1) and not w[:, :2048].any()
+            np.testing.assert_array_equal(w[:, 2048:, 0, 0], np.eye(2048, dtype=np.float32))
+            assert arg["curr_fc6_weight"] is arg["fc6_weight"]
+        else:
+            assert w.shape == (19, 38, 1, 1) and 0.005 < float(w.std()) < 0.02
+        if cls is accel_50:
+            assert float(arg["curr_fc6_weight"][0, 0, 0, 0]) == 6.0 and arg["curr_upsampling_weight"] is arg["50_upsampling_weight"]
+        if cls is accel_18:
+            assert "curr_fc6_weight" not in arg
