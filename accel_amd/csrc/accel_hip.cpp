@@ -420,8 +420,10 @@ static int finalize_conv(accel_plan* p, Op& op)
         c.w_class_stride = (size_t)rows * c.K_pad;
         c.Ho = op.a.H; c.Wo = op.a.W;
         c.yH = op.b.H; c.yW = op.b.W;
-        if (op.b.H != 2 * op.a.H || op.b.W != 2 * op.a.W)
-            return fail(ACCEL_ERR_PLAN, "deconv2x %s: output must be exactly 2x the input", op.name.c_str());
+        // 4x4/2 pad 1 gives exactly 2h x 2w; the reference's "pad 0 + Crop(offset 1) to the skip tensor" may keep one row /
+        // column less when the skip tensor has an odd size (frame sizes that are not multiples of 128): 2h-1 / 2w-1
+        if (op.b.H > 2 * op.a.H || op.b.H < 2 * op.a.H - 1 || op.b.W > 2 * op.a.W || op.b.W < 2 * op.a.W - 1)
+            return fail(ACCEL_ERR_PLAN, "deconv2x %s: output must be 2x the input (or one row / column less)", op.name.c_str());
     } else {
         int wkh = kh, wkw = kw;
         if (cols) kv_pair(kv, "wk", wkh, wkw, 3, 3);
@@ -557,6 +559,23 @@ static int finalize_conv(accel_plan* p, Op& op)
         } else if (c.force_tile == CONV_TILE_WINO) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
                                        "size and channels in multiples of 8 only", op.name.c_str());
+        }
+    }
+    {
+        // direct stem kernel (7x7 / stride 2 / pad 3, 3-channel image, 64 output channels): per-lane weight arrangement
+        const char* se = getenv("ACCEL_STEM");
+        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_STEM;
+        c.Cout_store = cout_store;
+        c.res = op.d.set ? op.d.ptr : nullptr;
+        if (want && !cols && cin == 3 && cout == 64 && conv_stem_eligible(c)) {
+            std::vector<float> ws((size_t)conv_stem_pack_floats(), 0.f);
+            conv_stem_pack(w->data.data(), cout, ws.data());
+            void* dsw = nullptr;
+            if ((rc = dev_upload(p, ws.data(), ws.size() * sizeof(float), &dsw))) return rc;
+            c.wstem = static_cast<const float*>(dsw);
+        } else if (c.force_tile == CONV_TILE_STEM) {
+            return fail(ACCEL_ERR_ARG, "conv %s: the stem kernel takes 7x7 / stride 2 / pad 3 layers on 3-channel images with 64 "
+                                       "output channels only", op.name.c_str());
         }
     }
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
@@ -925,6 +944,7 @@ static int autotune_plan(accel_plan* p)
         else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
             if (c.wu) cs.push_back({CONV_TILE_WINO, 0, 0});
+            if (c.wstem) cs.push_back({CONV_TILE_STEM, 0, 0});
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
@@ -964,7 +984,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

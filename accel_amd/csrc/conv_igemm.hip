@@ -83,15 +83,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         int n, rem, oy, ox;
         divmod_small(m, HoWo, inv_howo, n, rem);
         divmod_small(rem, p.Wo, inv_wo, oy, ox);
-        return (unsigned)((n * p.yH + (2 * oy + py)) * p.yW + (2 * ox + px));
+        const int yy = 2 * oy + py, xx = 2 * ox + px;
+        if (yy >= p.yH || xx >= p.yW) return OOB;      // output cropped to 2h-1 / 2w-1 (Crop after a pad-0 deconvolution)
+        return (unsigned)((n * p.yH + yy) * p.yW + xx);
     };
+    // Vector-memory operations retire IN ORDER through one counter: a residual load issued behind an output store cannot
+    // be consumed before that store has been acknowledged.  Loading the residual group by group between the stores
+    // (the obvious loop) therefore serialises 16*MI*NI/4 store round trips per wavefront -- measured as 4-11 us of
+    // epilogue on 42 us residual layers.  So: every per-channel constant and EVERY residual value is fetched before the
+    // first store is issued; after that the epilogue only computes and stores.
+    float sc[NI], sf[NI], sc2[NI], sf2[NI];
+    bool cok[NI];
+    int co[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int co = n0 + (wn * NI + j) * 32 + (lane & 31);
-        const bool cok = co < p.Cout_store;
-        const int cc = cok ? co : 0;
-        const float sc = p.scale[cc], sf = p.shift[cc];
-        const float sc2 = p.y2 ? p.scale2[cc] : 1.f, sf2 = p.y2 ? p.shift2[cc] : 0.f;
+        co[j] = n0 + (wn * NI + j) * 32 + (lane & 31);
+        cok[j] = co[j] < p.Cout_store;
+        const int cc = cok[j] ? co[j] : 0;
+        sc[j] = p.scale[cc]; sf[j] = p.shift[cc];
+        sc2[j] = p.y2 ? p.scale2[cc] : 1.f; sf2[j] = p.y2 ? p.shift2[cc] : 0.f;
+    }
+    if (p.res) {
+        float rv[MI][NI][16];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
+                    rv[i][j][e] = buf_load1(rr, (cok[j] && px_ != OOB) ? (px_ * p.resCs + co[j]) * 4u : OOB);
+                }
+        // accumulators become acc*scale + shift + residual here, so the store loop below is shared with the plain case
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][j][e];
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -101,27 +133,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned px_ = pixel_of(rbase + i * 32 + e + 8 * h);
-                    pix[e] = cok ? px_ : OOB;
-                    v[e] = acc[i][j][h * 4 + e] * sc + sf;
-                }
-                if (p.res) {
-                    float rv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        rv[e] = buf_load1(rr, pix[e] != OOB ? (pix[e] * p.resCs + co) * 4u : OOB);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    pix[e] = cok[j] ? px_ : OOB;
+                    v[e] = p.res ? acc[i][j][h * 4 + e] : acc[i][j][h * 4 + e] * sc[j] + sf[j];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
                     else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-                    buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co) * 4u : OOB, v[e]);
+                    buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co[j]) * 4u : OOB, v[e]);
                 }
                 if (p.y2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co) * 4u : OOB, fmaxf(v[e] * sc2 + sf2, 0.f));
+                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, fmaxf(v[e] * sc2[j] + sf2[j], 0.f));
                 }
             }
         }
@@ -770,7 +794,9 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
         const int HoWo = p.Ho * p.Wo;
         const int n = m / HoWo, rem = m - n * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        pix = ((size_t)n * p.yH + (2 * oy + (cls >> 1))) * p.yW + (2 * ox + (cls & 1));
+        const int yy = 2 * oy + (cls >> 1), xx = 2 * ox + (cls & 1);
+        if (yy >= p.yH || xx >= p.yW) return;           // cropped output row / column
+        pix = ((size_t)n * p.yH + yy) * p.yW + xx;
     }
     const int co = c4 * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co);
@@ -897,7 +923,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if (tile >= 20 && tile <= 30) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO;
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM;
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
@@ -918,7 +944,7 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
-    if (tile == CONV_TILE_WINO) return 0;      // the Winograd kernel never splits K
+    if (tile == CONV_TILE_WINO || tile == CONV_TILE_STEM) return 0;      // the Winograd / stem kernels never split K
     tile_dims(tile, bm, bn);
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
@@ -943,6 +969,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
+    if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.f16) {      // fp16-MFMA path: geometry ids 0-4 / 10-12 map onto the same tile shapes
         switch (conv_pick_tile(p)) {
             case 0: case 5: return launch_f16<128, 128, 2, 2>(p, st);

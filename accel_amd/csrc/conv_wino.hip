@@ -248,15 +248,28 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t y2r = make_rsrc(p.y2 ? p.y2 : p.y, p.y2 ? p.y2_bytes : 0u);
     const float inv_thw = 1.0f / (float)THW, inv_tw = 1.0f / (float)TW;
+    // Vector-memory operations retire in order through one counter, so a residual load issued behind an output store
+    // waits for that store's acknowledgement: ALL residual values are fetched before the first store.
+    bool okS[2];
+    unsigned pixS[2][4];
+    f32x4 rv[2][4];
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI) {
         const int tg = m0 + wm * 32 + sI * 16 + frow;
         int n, rem, ty, tx;
         divmod_small(tg < T ? tg : 0, THW, inv_thw, n, rem);
         divmod_small(rem, TW, inv_tw, ty, tx);
-        const bool ok = cok && tg < T;
+        okS[sI] = cok && tg < T;
         const unsigned pix00 = (unsigned)((n * p.Ho + 2 * ty) * p.Wo + 2 * tx);
-        const unsigned pixo[4] = {pix00, pix00 + 1, pix00 + (unsigned)p.Wo, pix00 + (unsigned)p.Wo + 1};
+        pixS[sI][0] = pix00; pixS[sI][1] = pix00 + 1; pixS[sI][2] = pix00 + (unsigned)p.Wo; pixS[sI][3] = pix00 + (unsigned)p.Wo + 1;
+        if (p.res) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rv[sI][o] = buf_load4(rr, okS[sI] ? (pixS[sI][o] * p.resCs + co) * 4u : OOB);
+        }
+    }
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+        const bool ok = okS[sI];
         f32x4 v[4];                          // [output pixel of the 2x2 tile][channel]
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -274,11 +287,8 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
             v[3][e] = (s1[1] - s1[2] - s1[3]) * sc[e] + sf[e];
         }
         if (p.res) {
-            f32x4 rv[4];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) rv[o] = buf_load4(rr, ok ? (pixo[o] * p.resCs + co) * 4u : OOB);
-#pragma unroll
-            for (int o = 0; o < 4; ++o) v[o] += rv[o];
+            for (int o = 0; o < 4; ++o) v[o] += rv[sI][o];
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                 if (p.act == 1) v[o][e] = fmaxf(v[o][e], 0.f);
                 else if (p.act == 2) v[o][e] = v[o][e] > 0.f ? v[o][e] : v[o][e] * p.slope;
             }
-            buf_store4(yr, ok ? (pixo[o] * p.yCs + co) * 4u : OOB, v[o]);
+            buf_store4(yr, ok ? (pixS[sI][o] * p.yCs + co) * 4u : OOB, v[o]);
         }
         if (p.y2) {
 #pragma unroll
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                 f32x4 u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[o][e] * sc2[e] + sf2[e], 0.f);
-                buf_store4(y2r, ok ? (pixo[o] * p.y2Cs + co) * 4u : OOB, u);
+                buf_store4(y2r, ok ? (pixS[sI][o] * p.y2Cs + co) * 4u : OOB, u);
             }
         }
     }

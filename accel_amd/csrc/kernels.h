@@ -44,6 +44,8 @@ struct ConvParams {
     unsigned wu_bytes;
     int wino_rows;         // output-channel rows of wu (Cout_store rounded up to the block's 64)
     int wino_T;            // 2x2 output tiles = M / 4, filled by the launcher
+    // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
+    const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
@@ -55,6 +57,11 @@ bool conv_wino_eligible(const ConvParams& p);
 int conv_wino_rows(int cout_store);
 void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, float* out);
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
+#define CONV_TILE_STEM 50
+bool conv_stem_eligible(const ConvParams& p);
+void conv_stem_pack(const float* w, int Cout, float* out);
+int conv_stem_pack_floats();
+hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns workspace bytes
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------

@@ -373,8 +373,9 @@ class Lowering(object):
                 if n.op == "Crop" and n.attrs["offset"] == (1, 1) and cur is A:
                     _, _, h, w = self.shape(n)
                     _, _, hi, wi = self.shape(x)
-                    if (h, w) != (2 * hi, 2 * wi):
-                        raise NotImplementedError("Crop %s after 4x4/2 deconvolution must be exactly 2x the input" % n.name)
+                    if h not in (2 * hi, 2 * hi - 1) or w not in (2 * wi, 2 * wi - 1):
+                        raise NotImplementedError("Crop %s after 4x4/2 deconvolution must keep 2x the input (or one row / "
+                                                  "column less)" % n.name)
                     cropped = True
                     cur = n
                     chain.append(n)

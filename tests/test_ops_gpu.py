@@ -312,3 +312,22 @@ def test_conv2d_winograd_rejects_other_geometries(ctx):
         ctx.conv2d(rnd(72, 1, 64, 7, 9), w, None, 1, 1, 1, tile=40)       # odd output size
     with pytest.raises(AccelError, match="not part of this build"):
         ctx.conv2d(x, w, None, 1, 1, 1, tile=21)                          # timing-only ablation id: diagnostics build only
+
+
+# ---- direct 7x7/2 stem kernel (launch geometry id 50, conv_stem.hip) -----------------------------------------------------
+@pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 50, 70), (1, 16, 128), (3, 37, 131), (1, 128, 256)])
+def test_conv2d_stem_kernel_matches_oracle(ctx, N, H, W):
+    x, w, b = rnd(80, N, 3, H, W, scale=50.0), rnd(81, 64, 3, 7, 7, scale=(2.0 / 147) ** 0.5 / 50.0), rnd(82, 64)
+    ref = O.conv2d(x, w, b, 2, 3, 1)
+    close(ctx.conv2d(x, w, b, 2, 3, 1, tile=50), ref)
+    scale, shift = rnd(83, 64), rnd(84, 64)
+    ref2 = O.relu(O.conv2d(x, w, None, 2, 3, 1) * scale[None, :, None, None] + shift[None, :, None, None])
+    close(ctx.conv2d(x, w, None, 2, 3, 1, scale=scale, shift=shift, act=1, tile=50), ref2)
+
+
+def test_conv2d_stem_kernel_rejects_other_layers(ctx):
+    from accel_amd.runtime import AccelError
+    with pytest.raises(AccelError, match="stem kernel"):
+        ctx.conv2d(rnd(85, 1, 6, 32, 32), rnd(86, 64, 6, 7, 7), None, 2, 3, 1, tile=50)       # FlowNet's 6-channel stem
+    with pytest.raises(AccelError, match="stem kernel"):
+        ctx.conv2d(rnd(87, 1, 3, 32, 32), rnd(88, 32, 3, 7, 7), None, 2, 3, 1, tile=50)       # 32 output channels
