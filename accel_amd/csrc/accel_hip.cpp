@@ -834,6 +834,7 @@ struct TuneVal { int tile, split_target, no_split; };
 static std::map<TuneKey, TuneVal> g_tune_cache;
 static std::map<TuneKey, TuneVal> g_tune_shipped;      // entries of the in-tree table (never written back to the user file)
 static bool g_tune_loaded = false;
+static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a table / taken by timing in this process
 
 // Launch-geometry decisions are persisted so that they are REPRODUCIBLE: the summation order of a convolution (tile,
 // split-K) decides its last bits, and a decision taken by timing can differ from process to process.
@@ -1016,6 +1017,9 @@ static int autotune_plan(accel_plan* p)
             if (rc) break;
             it = g_tune_cache.insert({key, bv}).first;
             tuned_any = true;
+            ++g_tune_timed;
+        } else {
+            ++g_tune_hits;
         }
         conv_apply(c, it->second.tile, it->second.split_target, it->second.no_split);
     }
@@ -1028,6 +1032,15 @@ static int autotune_plan(accel_plan* p)
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+extern "C" int accel_tune_stats(int* replayed, int* timed, int* shipped_entries)
+{
+    tune_cache_load();
+    if (replayed) *replayed = g_tune_hits;
+    if (timed) *timed = g_tune_timed;
+    if (shipped_entries) *shipped_entries = (int)g_tune_shipped.size();
+    return 0;
+}
+
 extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
 {
     if (!out) return fail(ACCEL_ERR_ARG, "accel_ctx_create: out is NULL");

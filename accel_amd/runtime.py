@@ -52,6 +52,7 @@ def _declare(lib):
         "accel_model_has_param": [vp, c.c_char_p],
         "accel_model_add_plan": [vp, c.c_char_p, c.c_char_p, c.POINTER(vp)],
         "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
+        "accel_tune_stats": [c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],
         "accel_plan_num_ops": [vp],
@@ -101,6 +102,13 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         EXPORTS = _declare(_lib)
     return _lib
+
+
+def tune_stats():
+    """(decisions replayed from a table, decisions taken by timing, entries of the shipped table) of this process"""
+    a, b, c_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib().accel_tune_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c_))
+    return a.value, b.value, c_.value
 
 
 def check(rc):

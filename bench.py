@@ -201,6 +201,7 @@ class Workload(object):
         (accel_plan_profile), all conv launches of one clip (1 key + interval-1 non-key plans)"""
         kms, cms = self.key.profile(2), self.cur.profile(2)
         fl = ms = n = by = 0.0
+        fam = {}
         for plan, t, wgt in ((self.key, kms, 1), (self.cur, cms, self.interval - 1)):
             for op, d in zip(plan.ops(), t):
                 if op["kind"] == "conv":
@@ -208,14 +209,26 @@ class Workload(object):
                     by += wgt * op["bytes"]
                     ms += wgt * float(d)
                     n += wgt
+                    name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_f32_kernel" if op["tile"] == 40
+                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv_igemm_f16_kernel" if dtype != "f32" else "conv_igemm_f32_kernel")
+                    f = fam.setdefault(name, [0.0, 0.0, 0.0])
+                    f[0] += wgt; f[1] += wgt * float(d); f[2] += wgt * op["flops"]
         clip_ms = float(kms.sum()) + (self.interval - 1) * float(cms.sum())
         ach = fl / (ms * 1e-3) / 1e12
         peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+        families = {k: {"launches_per_step": int(v[0]), "avg_launch_us": round(1e3 * v[1] / v[0], 2), "ms_per_step": round(v[1], 3),
+                        "algorithmic_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0} for k, v in sorted(fam.items())}
+        if "conv_wino_f32_kernel" in families:
+            families["conv_wino_f32_kernel"]["note"] = ("Winograd F(2x2,3x3): executes 16/36 of the multiply-adds of the direct convolution "
+                                                        "whose flops are counted here, so the algorithmic rate may exceed the matrix-core peak; "
+                                                        "executed rate = algorithmic / 2.25")
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "traffic_note": None, "algorithmic_bytes_per_launch": round(by / n),
-                "kernel": "conv_igemm_f32_kernel (all tile variants)" if dtype == "f32" else "conv_igemm_f16_kernel",
-                "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
-                "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)}
+                "kernel": "convolution kernels of the path (implicit GEMM + Winograd F(2x2,3x3) + 7x7 stem + narrow-N), per family below",
+                "achieved_note": "ALGORITHMIC flops (2 x MAC of the direct convolution after the two exact linear folds of DESIGN.md 4) of all conv "
+                                 "launches of one step / the sum of their HIP-event durations",
+                "families": families, "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
+                "gflop_per_launch": round(fl / n / 1e9, 3), "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)}
 
     def close(self):
         if self.gather is not None:

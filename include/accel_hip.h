@@ -84,6 +84,11 @@ int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double*
 /* launch decisions of op i after finalize (autotuned or heuristic): conv tile id (conv_igemm.hip, -1 for
  * non-conv ops), split-K factor, 1 if the narrow-N kernel runs it.  Diagnostic only. */
 int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narrow);
+/* Launch geometries are REPRODUCIBLE: decisions come from the table shipped beside the library (tune/gfx950.tune, covers
+ * the BASELINE workloads) or from the user's table ($ACCEL_TUNE_CACHE, else ~/.cache/accel_amd/gfx950.tune); a shape in
+ * neither is timed once and appended to the user's table.  Counters of this process: decisions replayed, decisions
+ * taken by timing, entries of the shipped table (0 = not found).  Diagnostic only. */
+int accel_tune_stats(int* replayed, int* timed, int* shipped_entries);
 /* runs the plan `iters` times eagerly with a HIP event pair around every op on
  * the context stream; ms[i] = mean duration of op i */
 int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);

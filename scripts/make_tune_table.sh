@@ -1,0 +1,18 @@
+#!/bin/bash
+# Regenerates the shipped launch-geometry table accel_amd/tune/gfx950.tune on a GPU box (through gpurun):
+#   bash scripts/make_tune_table.sh   -> gpurun_out/gfx950.tune, to be copied to accel_amd/tune/gfx950.tune
+# Every workload the BASELINE configs and bench.py bind is bound once with timing-based selection; the decisions are
+# then replayed by every later process (accel_hip.cpp, "Launch-geometry decisions are persisted").
+set -u
+REPO=$(pwd)
+export ACCEL_TUNE_SHIPPED=0 ACCEL_TUNE_CACHE=$REPO/gpurun_out/gfx950.tune
+rm -f $ACCEL_TUNE_CACHE
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> gpurun_out/tune_table.err          # Accel-18 B=8, B=1, Accel-101 B=8
+for v in 34 50 101; do
+  python bench.py --version $v --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
+done
+for v in 34 50; do
+  python bench.py --version $v --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
+done
+python bench.py --size 512x1024 --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
+wc -l $ACCEL_TUNE_CACHE

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile recipe (run on the GPU box through gpurun; outputs under gpurun_out/, summaries are then copied
 # to profiles/ by hand):  bash scripts/profile_round.sh r01
-# 1. plain bench (writes the autotune cache so the profiled runs launch no tuning candidates)
+# 1. plain bench (headline + secondaries)
 # 2. rocprofv3 --kernel-trace --stats of the same command (two-stream default, then ACCEL_MULTI_STREAM=0)
 # 3. three separate --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE), never combined with the trace domains
 # 4. per-op HIP-event timings of both plans
@@ -10,10 +10,10 @@ R=${1:-r01}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-export ACCEL_TUNE_CACHE=$OUT/tune_$R.txt
+# launch geometries come from the shipped table (accel_amd/tune/gfx950.tune): no tuning launches in any of the runs below
 python bench.py > $OUT/bench_${R}_final.json 2> $OUT/bench_${R}_final.err
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+B="python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --secondary none"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$R -o bench --output-format csv -- $B > $OUT/prof_${R}_bench.json 2>/dev/null
 ACCEL_MULTI_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_1s -o bench --output-format csv -- $B > $OUT/prof_${R}_1s_bench.json 2>/dev/null
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/prof_${R}_pmc1 -o bench --output-format csv -- $B > /dev/null 2>&1

@@ -3,8 +3,8 @@
 
   python scripts/summarize_rocprof.py <stats_dir> <pmc_sq_dir> <pmc_fetch_dir> <pmc_write_dir> [traffic.json] > profiles/rNN_summary.md
 
-With a fifth argument the HBM traffic per launch of the conv_igemm_f32 family (all tile variants, launch-weighted) is
-also written as JSON; bench.py reports it as `roofline.traffic` for the same workload.
+With a fifth argument the HBM traffic per launch of the convolution kernels (implicit-GEMM tile variants, Winograd,
+stem, narrow-N; launch-weighted) is also written as JSON; bench.py reports it as `roofline.traffic` for the same workload.
 
 PMC passes are separate runs (SQ counters / FETCH_SIZE / WRITE_SIZE cannot share
 a pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Corrections applied as that
@@ -63,16 +63,18 @@ def main():
 
 
     if len(sys.argv) > 5:
-        fam = "conv_igemm_f32_kernel"
-        rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if fam in k) * 2 * 1024
-        nr = sum(n for k, n in nf.items() if fam in k)
-        ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if fam in k) * 1024
-        nwr = sum(n for k, n in nw.items() if fam in k)
+        fams = ("conv_igemm_f32_kernel", "conv_wino_f32_kernel", "conv_stem_f32_kernel", "conv_narrow_kernel", "conv_igemm_f16_kernel")
+        fam = "convolution kernels: " + ", ".join(fams)
+        is_conv = lambda k: any(f in k for f in fams)
+        rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if is_conv(k)) * 2 * 1024
+        nr = sum(n for k, n in nf.items() if is_conv(k))
+        ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if is_conv(k)) * 1024
+        nwr = sum(n for k, n in nw.items() if is_conv(k))
         extra = dict(a.split("=", 1) for a in sys.argv[6:] if "=" in a)      # e.g. batch=4: the workload the passes ran
         json.dump({"kernel": fam + " (all tile variants)", "batch": int(extra.get("batch", 1)), "read_bytes_per_launch": rd / max(nr, 1),
                    "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr,
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 8 "
-                             "--warmup 2 --no-cpu-baseline`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "
+                             "--warmup 2 --no-cpu-baseline --secondary none`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "
                              "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"},
                   open(sys.argv[5], "w"), indent=1)
 

@@ -225,3 +225,29 @@ def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
         assert float(np.abs(a - b).mean()) <= 1e-2 * scale, "frame %d" % t
         assert float((la != lb).mean()) < 1e-2, "frame %d" % t
         assert len(np.unique(la)) > 1
+
+
+def test_headline_launch_geometries_are_replayed_not_timed(demo_cfg):
+    """Reproducibility of the summation order: binding the headline workload (Accel-18, 1024x2048, one clip per call)
+    takes every launch geometry from the shipped table -- no decision by timing -- and two independently bound
+    models give bit-identical logits."""
+    from accel_amd import demo, runtime
+    from accel_amd.core import tester
+    H, W = 1024, 2048
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    data = demo.build_batches(synth.make_clip(H, W, 2), demo_cfg)
+    outs = []
+    try:
+        _, timed0, shipped = runtime.tune_stats()
+        assert shipped > 0, "accel_amd/tune/gfx950.tune not found beside the library"
+        for _ in range(2):
+            r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+            outs.append([r.step(i, data[i], 2)[0].asnumpy().copy() for i in range(2)])
+            r.close()
+        replayed, timed1, _ = runtime.tune_stats()
+        assert timed1 == timed0 and replayed > 0, "%d launch geometries were decided by timing" % (timed1 - timed0)
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        tester.release_models()

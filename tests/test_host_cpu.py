@@ -545,3 +545,19 @@ def test_init_weight_rules(demo_cfg):
             assert float(arg["curr_fc6_weight"][0, 0, 0, 0]) == 6.0 and arg["curr_upsampling_weight"] is arg["50_upsampling_weight"]
         if cls is accel_18:
             assert "curr_fc6_weight" not in arg
+
+
+def test_shipped_tune_table_loads():
+    """accel_amd/tune/gfx950.tune (launch geometries of the BASELINE workloads, regenerated by scripts/make_tune_table.sh)
+    carries the version tag the library expects and is picked up from beside libaccel_hip.so."""
+    import os
+    import re
+    from accel_amd import runtime
+    path = os.path.join(os.path.dirname(runtime.LIB_PATH), "tune", "gfx950.tune")
+    src = open(os.path.join(os.path.dirname(runtime.LIB_PATH), "csrc", "accel_hip.cpp")).read()
+    tag = re.search(r'#define ACCEL_TUNE_VERSION "([^"]+)"', src).group(1)
+    lines = open(path).read().splitlines()
+    assert lines[0] == "# " + tag
+    assert all(len(l.split()) == 19 for l in lines[1:]) and len(lines) > 100
+    replayed, timed, shipped = runtime.tune_stats()
+    assert shipped == len(lines) - 1 and timed == 0
