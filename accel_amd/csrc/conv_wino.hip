@@ -46,7 +46,7 @@ namespace {
 constexpr int TT = 64;                 // output tiles (2x2 pixels each) per block
 constexpr int KK = 64;                 // output channels per block
 constexpr int BKC = 8;                 // input channels per K step
-constexpr int MS = 2;                  // K steps whose input patches are loaded together (one 128-byte line of a pixel)
+constexpr int MS = 2;                  // K steps per unrolled macro step = depth of the patch-register ring
 constexpr int VPS = TT * BKC + 8;      // floats per position of the V image (+32 B: see header)
 constexpr int UPS = KK * BKC;          // floats per position of the U image
 constexpr int VSTAGE = 16 * VPS, USTAGE = 16 * UPS;
@@ -121,13 +121,13 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
     }
     const unsigned u_step = (unsigned)((size_t)16 * p.wino_rows * BKC * 4);      // bytes between K steps
 
-    // Patch loads are issued for MS = 4 K steps at once (the 32 channels = one 128-byte line of a pixel): the four
-    // 32-byte pieces of a line are then requested back to back and the last three hit the line in L1, instead of being
-    // requested a K step apart with ~100 KB of other traffic in between (the L1 holds 32 KB).
-    f32x4 d[MS][4];
-    auto load_one = [&](int k, int sl) {              // slot sl = (step within the macro step, patch row)
-        const int ms = sl >> 2, r = sl & 3;
-        d[ms][r] = buf_load4(xr, a_off[r] != OOB ? a_off[r] + (unsigned)(k + ms) * (BKC * 4) : OOB);
+    // Patch registers: a ring of 2 K steps.  Step k issues the 4 loads of step k+2 behind its first MFMAs; they are consumed
+    // by the transform that runs under the second half of step k+1 -- one and a half K steps (~4 us) of lead.  With half a
+    // step of lead, as in a first version, the transform stalled on these loads for 20 % of the kernel (ablation: 345 us
+    // with, 272 us without the transform consuming them; res4 branch2b x 8 clips).
+    f32x4 d[2][4];
+    auto load_ring = [&](int kstep_, int set_, int r) {      // patch row r of K step `kstep_` into ring set `set_` (= kstep_ & 1;
+        d[set_][r] = buf_load4(xr, a_off[r] != OOB ? a_off[r] + (unsigned)kstep_ * (BKC * 4) : OOB);     // a constant after unrolling)
     };
     auto issue_u_one = [&](int k, int buf, int e) {   // one of this wavefront's 4 weight DMAs of step k (1 KB each)
         const int idx = wave * 4 + e, pp = idx >> 1, hh = idx & 1;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                                                  u_off[e], (unsigned)k * u_step, 0, 0);
     };
     f32x4 vo;                                          // the float4 of V being assembled
-    auto transform_one = [&](int buf, int ms, int piece) {    // piece = (patch row i of V, channel c): 16 per step
+    auto transform_one = [&](int buf, int ms, int piece) {    // ms = ring set; piece = (patch row i of V, channel c): 16 per step
         const int i = piece >> 2, c = piece & 3;
         // B^T down the patch column, one channel:  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
         const float t = i == 0 ? d[ms][0][c] - d[ms][2][c] : i == 1 ? d[ms][1][c] + d[ms][2][c]
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
     // the first 8 (most of a step ahead of their first use), the 16 transform pieces (3 VALU each, one LDS store per 4)
     // behind MFMAs 32..47.  Scheduling fences pin that order; fragments of position p+1 are read before the MFMAs of
     // position p.  The partner wavefront of the SIMD fills the matrix pipe whenever this one waits.
-    // `sub` = (k + 1) % MS selects the patch registers of step k + 1; when it is 0, step k also issues the loads of the
-    // next macro step (steps k+1 .. k+MS) -- all of the previous macro step's registers have been consumed by then.
-    auto kstep = [&](int k, int cur, auto pipe, auto sub_) {
+    // K2 = k & 1 (compile time: the loop is unrolled by 2): LDS stage K2, transform of step k+1 from ring set K2 ^ 1, the 4
+    // patch loads of step k+2 into ring set K2 (consumed at step k-1).
+    auto kstep = [&](int k, auto k2_, auto pipe) {
         constexpr bool PIPE = decltype(pipe)::value;
-        constexpr int SUB = decltype(sub_)::value;
-        constexpr int NL = SUB == 0 ? 4 * MS : 0;       // patch-load slots of this step
+        constexpr int K2 = decltype(k2_)::value, cur = K2;
+        constexpr int NL = 4;                           // patch-load slots of this step
         const float* va = Vs + cur * VSTAGE;
         const float* ub = Us + cur * USTAGE + b_base;
         f32x2 fa0[2], fa1[2], fb[2];
@@ -196,42 +196,38 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                 acc[pp][sI] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c][kg], av, acc[pp][sI], 0, 0, 0);
                 if (PIPE) {
                     const int slot = pp * 4 + r;
-                    if (slot < NL) load_one(k + 1, slot);
+                    if (slot < NL) load_ring(k + 2, K2, slot);
                     else if (slot >= NL && slot < NL + 4) issue_u_one(k + 1, cur ^ 1, slot - NL);
-                    else if (slot >= 32 && slot < 48) transform_one(cur ^ 1, SUB, slot - 32);
+                    else if (slot >= 32 && slot < 48) transform_one(cur ^ 1, K2 ^ 1, slot - 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
 
-    const int nk = p.Cin / BKC;
+    const int nk = p.Cin / BKC;           // a multiple of 2 (conv_wino_eligible)
 #pragma unroll
-    for (int sl = 0; sl < 4 * MS; ++sl) load_one(0, sl);
+    for (int r = 0; r < 4; ++r) {
+        load_ring(0, 0, r);
+        load_ring(1, 1, r);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) issue_u_one(0, 0, e);
 #pragma unroll
     for (int pc = 0; pc < 16; ++pc) transform_one(0, 0, pc);
     wait_all_barrier();
-    // nk is a multiple of MS (conv_wino_eligible): whole macro steps, the last one ending with the unpipelined final step.
-    // k is a multiple of MS at the top of every macro step, so the LDS stage of each step is a compile-time constant.
     typedef std::true_type PIPE_T;
     typedef std::false_type LAST_T;
-#define WINO_STEP(s, pipe_t)                                                                           \
-    do {                                                                                               \
-        kstep(k + (s), (s) & 1, pipe_t(), std::integral_constant<int, ((s) + 1) % MS>());              \
-        if (pipe_t::value) wait_all_barrier();                                                         \
+#define WINO_STEP(s, pipe_t)                                                   \
+    do {                                                                       \
+        kstep(k + (s), std::integral_constant<int, (s)>(), pipe_t());          \
+        if (pipe_t::value) wait_all_barrier();                                 \
     } while (0)
     int k = 0;
-    for (; k + MS < nk; k += MS) {
-        WINO_STEP(0, PIPE_T);
-        if (MS > 1) WINO_STEP(1, PIPE_T);
-        if (MS > 2) WINO_STEP(2, PIPE_T);
-        if (MS > 3) WINO_STEP(3, PIPE_T);
+    for (; k + 2 < nk; k += 2) {
+        WINO_STEP(0, PIPE_T); WINO_STEP(1, PIPE_T);
     }
-    if (MS == 1) WINO_STEP(0, LAST_T);
-    if (MS == 2) { WINO_STEP(0, PIPE_T); WINO_STEP(1, LAST_T); }
-    if (MS == 4) { WINO_STEP(0, PIPE_T); WINO_STEP(1, PIPE_T); WINO_STEP(2, PIPE_T); WINO_STEP(3, LAST_T); }
+    WINO_STEP(0, PIPE_T); WINO_STEP(1, LAST_T);
 #undef WINO_STEP
 
     // ---- output transform + fused epilogue ---------------------------------------------------------------------
