@@ -944,7 +944,14 @@ static int autotune_plan(accel_plan* p)
         if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
         else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
-            if (c.wu) cs.push_back({CONV_TILE_WINO, 0, 0});
+            if (c.wu) {
+                cs.push_back({CONV_TILE_WINO, 0, 0});
+                ConvParams q = c;
+                const size_t base = conv_apply(q, CONV_TILE_WINO, 0, 0);
+                const int ks0 = q.ksplit;
+                if (conv_apply(q, CONV_TILE_WINO, 1024, 0) && q.ksplit != ks0) cs.push_back({CONV_TILE_WINO, 1024, 0});
+                if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
+            }
             if (c.wstem) cs.push_back({CONV_TILE_STEM, 0, 0});
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");

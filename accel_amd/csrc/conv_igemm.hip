@@ -915,6 +915,13 @@ int conv_pick_tile(const ConvParams& p)
     return 3;
 }
 
+hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st)
+{
+    const long total = (long)classes * p.M * (p.Cout_store / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, classes);
+    return hipGetLastError();
+}
+
 int conv_tile_bk(int tile) { return tile == 13 ? 64 : tile == 15 ? 16 : 32; }
 
 // launch-geometry ids this build carries (all of them compute the same contraction)
@@ -944,7 +951,24 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
-    if (tile == CONV_TILE_WINO || tile == CONV_TILE_STEM) return 0;      // the Winograd / stem kernels never split K
+    if (tile == CONV_TILE_STEM) return 0;
+    if (tile == CONV_TILE_WINO) {
+        // Winograd blocks own 64 tiles (256 pixels) x 64 channels; the K loop runs in steps of 8 channels, unrolled by 2.
+        // Splitting it over blockIdx.y leaves raw partial OUTPUTS (the output transform is linear) that the ordinary
+        // split-K reduce kernel sums and finishes.
+        const long blocks = ((p.M / 4 + 63) / 64) * (long)conv_wino_rows(p.Cout_store) / 64;
+        const int KT = p.Cin / 8, min_steps = 4;
+        const int min_blocks = p.split_target > 0 ? p.split_target : 256;
+        const int target = p.split_target > 0 ? p.split_target : 512;
+        if (blocks >= min_blocks || KT < 2 * min_steps) return 0;
+        int want = (int)((target + blocks - 1) / blocks);
+        int ks = want < KT / min_steps ? want : KT / min_steps;
+        if (ks < 2) return 0;
+        p.kt_per_split = ((KT + ks - 1) / ks + 1) / 2 * 2;             // even: the K loop is unrolled by 2
+        p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
+        if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
+        return (size_t)p.ksplit * p.M * p.Cout_store * sizeof(float);
+    }
     tile_dims(tile, bm, bn);
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
 
     const int TH = p.Ho >> 1, TW = p.Wo >> 1, THW = TH * TW;
     const int T = p.wino_T;
+    const int kb = p.ksplit > 1 ? (int)blockIdx.y * p.kt_per_split : 0;       // first K step of this block
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ur = make_rsrc(p.wu, p.wu_bytes);
 
@@ -127,12 +128,12 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
     // with, 272 us without the transform consuming them; res4 branch2b x 8 clips).
     f32x4 d[2][4];
     auto load_ring = [&](int kstep_, int set_, int r) {      // patch row r of K step `kstep_` into ring set `set_` (= kstep_ & 1;
-        d[set_][r] = buf_load4(xr, a_off[r] != OOB ? a_off[r] + (unsigned)kstep_ * (BKC * 4) : OOB);     // a constant after unrolling)
+        d[set_][r] = buf_load4(xr, a_off[r] != OOB ? a_off[r] + (unsigned)(kb + kstep_) * (BKC * 4) : OOB);     // a constant after unrolling)
     };
     auto issue_u_one = [&](int k, int buf, int e) {   // one of this wavefront's 4 weight DMAs of step k (1 KB each)
         const int idx = wave * 4 + e, pp = idx >> 1, hh = idx & 1;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (lds_void_ptr)(Us + buf * USTAGE + pp * UPS + hh * 256), 16,
-                                                 u_off[e], (unsigned)k * u_step, 0, 0);
+                                                 u_off[e], (unsigned)(kb + k) * u_step, 0, 0);
     };
     f32x4 vo;                                          // the float4 of V being assembled
     auto transform_one = [&](int buf, int ms, int piece) {    // ms = ring set; piece = (patch row i of V, channel c): 16 per step
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
         }
     };
 
-    const int nk = p.Cin / BKC;           // a multiple of 2 (conv_wino_eligible)
+    // split-K: blockIdx.y owns K steps [kb, kb + nk) (nk even), and leaves raw partial outputs in the workspace
+    const int nk_all = p.Cin / BKC;       // a multiple of 2 (conv_wino_eligible)
+    const int nk = p.ksplit > 1 ? min(p.kt_per_split, nk_all - kb) : nk_all;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         load_ring(0, 0, r);
@@ -258,10 +261,36 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
         okS[sI] = cok && tg < T;
         const unsigned pix00 = (unsigned)((n * p.Ho + 2 * ty) * p.Wo + 2 * tx);
         pixS[sI][0] = pix00; pixS[sI][1] = pix00 + 1; pixS[sI][2] = pix00 + (unsigned)p.Wo; pixS[sI][3] = pix00 + (unsigned)p.Wo + 1;
-        if (p.res) {
+        if (p.res && p.ksplit <= 1) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) rv[sI][o] = buf_load4(rr, okS[sI] ? (pixS[sI][o] * p.resCs + co) * 4u : OOB);
         }
+    }
+    if (p.ksplit > 1) {
+        // raw partial outputs of this K slice: ws[split][pixel][Cout_store]; scale/shift, residual and activation
+        // are applied by the reduce kernel after summing the slices
+        const size_t slab = (size_t)blockIdx.y * p.M * p.Cout_store;
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.ws + slab, (unsigned)((size_t)p.M * p.Cout_store * 4));
+#pragma unroll
+        for (int sI = 0; sI < 2; ++sI) {
+            f32x4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    s0[jj] = acc[jj][sI][e] + acc[4 + jj][sI][e] + acc[8 + jj][sI][e];
+                    s1[jj] = acc[4 + jj][sI][e] - acc[8 + jj][sI][e] - acc[12 + jj][sI][e];
+                }
+                v[0][e] = s0[0] + s0[1] + s0[2];
+                v[1][e] = s0[1] - s0[2] - s0[3];
+                v[2][e] = s1[0] + s1[1] + s1[2];
+                v[3][e] = s1[1] - s1[2] - s1[3];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) buf_store4(wr, okS[sI] ? (pixS[sI][o] * p.Cout_store + co) * 4u : OOB, v[o]);
+        }
+        return;
     }
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI) {
@@ -351,6 +380,11 @@ hipError_t launch_conv_wino(const ConvParams& p0, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(p.MT * p.NT), dim3(512), WINO_LDS, st, p);
+    hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(512), WINO_LDS, st, p);
+    if (p.ksplit > 1) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_splitk_reduce(p, 1, st);
+    }
     return hipGetLastError();
 }

@@ -57,6 +57,7 @@ bool conv_wino_eligible(const ConvParams& p);
 int conv_wino_rows(int cout_store);
 void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, float* out);
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
+hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st);   // sums ws[split][class][M][Cout_store] + epilogue
 #define CONV_TILE_STEM 50
 bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);

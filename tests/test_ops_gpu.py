@@ -273,6 +273,7 @@ WINO_CASES = [
     (1, 16, 40, 6, 6),          # shortest K loop (2 steps), 9 tiles
     (2, 512, 64, 4, 8),         # deep K, low resolution
     (1, 64, 18, 12, 20),        # 18-channel offset conv shape
+    (2, 64, 128, 128, 256),     # 512 blocks: the un-split path (smaller grids split K over blockIdx.y, reduce kernel finishes)
 ]
 
 
