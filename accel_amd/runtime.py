@@ -93,9 +93,32 @@ def _declare(lib):
 EXPORTS = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (same soname as the system's).  Whichever copy a process loads
+    first serves both users; when the SYSTEM copy came first, torch's later CUDA initialisation failed on this image
+    ("No HIP GPUs are available": torch 2.10+rocm7.0 against the ROCm 7.2 runtime), while libaccel_hip runs fine on
+    torch's copy.  So if torch is installed but not imported yet, its runtime is loaded before libaccel_hip.so --
+    located through the import machinery, torch itself is NOT imported -- and any order of use works
+    (tests/test_configs_gpu.py::test_torch_initialises_after_the_library).  ACCEL_SYSTEM_HIP=1 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("ACCEL_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _lib, EXPORTS
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise AccelError("libaccel_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                              "accel_amd has no CPU fallback")

@@ -251,3 +251,25 @@ def test_headline_launch_geometries_are_replayed_not_timed(demo_cfg):
             np.testing.assert_array_equal(a, b)
     finally:
         tester.release_models()
+
+
+def test_torch_initialises_after_the_library():
+    """One process, libaccel_hip first, torch.cuda afterwards (the order of a script that only later sets up
+    torch.distributed for the gather): both must work -- runtime.lib() makes the two share ONE HIP runtime."""
+    import subprocess
+    import sys
+    code = ("import numpy as np\n"
+            "from accel_amd import runtime\n"
+            "ctx = runtime.Context(0)\n"
+            "y = ctx.conv2d(np.ones((1, 8, 8, 8), np.float32), np.ones((8, 8, 3, 3), np.float32), None, 1, 1, 1)\n"
+            "assert float(y[0, 0, 4, 4]) == 72.0\n"
+            "import torch\n"
+            "torch.cuda.set_device(0)\n"
+            "t = torch.ones(4, device='cuda') * 2\n"
+            "assert float(t.sum()) == 8.0\n"
+            "y2 = ctx.conv2d(np.ones((1, 8, 8, 8), np.float32), np.ones((8, 8, 3, 3), np.float32), None, 1, 1, 1)\n"
+            "assert float(y2[0, 0, 0, 0]) == 32.0\n"
+            "print('both fine')\n")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "both fine" in out.stdout, out.stderr[-2000:]
