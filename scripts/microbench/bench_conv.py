@@ -42,6 +42,11 @@ if __import__('os').environ.get("WINO"):     # the 3x3 / stride-1 layers of the 
     for (n, ci, co, h, w, rs) in base:
         SHAPES.append((n + " x1", ci, co, h, w, 3, 1, 1, 1, rs, "conv"))
         SHAPES.append((n + " x8", ci, co, 8 * h, w, 3, 1, 1, 1, rs, "conv"))
+if __import__('os').environ.get("SHORTK"):   # short-K residual 1x1 layers at 8 clips per call (rows stacked)
+    SHAPES = [("res4_2c 1x1 256-1024 +res x8", 256, 1024, 512, 128, 1, 1, 0, 1, 1, "conv"),
+              ("res3_2c 1x1 128-512 +res x8", 128, 512, 1024, 256, 1, 1, 0, 1, 1, "conv"),
+              ("res2_2c 1x1 64-256 +res x8", 64, 256, 2048, 512, 1, 1, 0, 1, 1, "conv"),
+              ("res4_2a 1x1 1024-256 x8", 1024, 256, 512, 128, 1, 1, 0, 1, 0, "conv")]
 if __import__('os').environ.get("KSWEEP"):   # time vs K at fixed M, N: slope = steady-state rate, intercept = fixed cost per launch
     SHAPES = [("K=%d N=256 M=8192" % k, k, 256, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 64, 128, 256, 512, 1024, 2304, 4608, 8192)]
     SHAPES += [("K=%d N=1024 M=8192" % k, k, 1024, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 256, 1024, 4096)]

@@ -7,6 +7,8 @@ Tolerance: |logit - oracle| <= 1e-3 * max(1, max|oracle logit|)  (BASELINE.json:
 top-2 margin exceeds twice the MEASURED logit error of the frame (inside that band
 a tie can legitimately flip), and the mismatch fraction overall must stay below
 0.1 %.  tests/parity_report.py logs the margin histogram of every frame."""
+import os
+
 import numpy as np
 import pytest
 
@@ -473,3 +475,50 @@ def test_train_symbol_forward(demo_cfg, version, key_interval):
     srt = np.sort(ref["softmax_output"], axis=1)
     safe = ((srt[:, -1] - srt[:, -2]) > 1e-3)[0]
     np.testing.assert_array_equal(lab[0][safe], np.argmax(ref["softmax_output"], axis=1)[0][safe])
+
+
+def test_demo_end_to_end_on_a_cityscapes_layout(tmp_path, demo_cfg, capsys):
+    """`python -m accel_amd.demo --data DIR --params A B --out DIR` end to end (dff_deeplab/demo.py:107-284) on a directory
+    laid out like Cityscapes (leftImg8bit_sequence/val/<city>/<city>_<seq>_<frame>_leftImg8bit.png, 30-frame snippets with
+    the label on frame 19; gtFine/val/<city>/..._gtFine_trainIds.png) and two MXNet-format checkpoints that are merged
+    like demo.py:192-195.  The ground truth of every labelled frame is the oracle's own label map, so the printed mIoU
+    must be 100 -- frame selection, city-keyed label lookup, checkpoint merge, inference and evaluator in one pass."""
+    from PIL import Image
+    from accel_amd import demo
+    from accel_amd.core import tester
+    from accel_amd.utils import load_model
+    H, W, interval, num_ex = 128, 256, 3, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    flow_names = [k for k in arg if k.startswith(("flow_", "conv2", "conv3", "conv4", "conv5", "conv6", "Convolution", "deconv", "upsample_flow"))]
+    load_model.save_checkpoint(str(tmp_path / "accel-18"), 0, {k: v for k, v in arg.items() if k not in flow_names}, aux)
+    load_model.save_checkpoint(str(tmp_path / "flownet"), 0, {k: arg[k] for k in flow_names}, {})
+    cities = ["frankfurt", "lindau"]
+    P = dict(arg)
+    P.update(aux)
+    for ci, city in enumerate(cities[:num_ex]):
+        seq = tmp_path / "data" / "leftImg8bit_sequence" / "val" / city
+        gt = tmp_path / "data" / "gtFine" / "val" / city
+        seq.mkdir(parents=True)
+        gt.mkdir(parents=True)
+        clip = synth.make_clip(H, W, 30, seed=900 + ci)
+        for t, f in enumerate(clip):
+            Image.fromarray(f[:, :, ::-1]).save(str(seq / ("%s_000000_%06d_leftImg8bit.png" % (city, t))))
+        # the demo keeps frames 19-(interval-1) .. 19 of the snippet: key frame first, labelled frame last
+        sel = clip[19 - (interval - 1):20]
+        ref = G.run_clip(P, "18", _oracle_frames(sel, demo_cfg), interval)
+        Image.fromarray(ref[-1][1][0].astype(np.uint8)).save(str(gt / ("%s_000000_000019_gtFine_trainIds.png" % city)))
+    try:
+        demo.main(["--version", "18", "--interval", str(interval), "--num_ex", str(num_ex), "--data", str(tmp_path / "data"),
+                   "--params", str(tmp_path / "accel-18-0000.params"), str(tmp_path / "flownet-0000.params"),
+                   "--out", str(tmp_path / "seg")])
+    finally:
+        tester.release_models()
+    out = capsys.readouterr().out
+    assert "===> final mIoU 100.000" in out, out[-1500:]
+    assert out.count("(cum) mIoU") == num_ex and "frames/s" in out
+    pngs = sorted(os.listdir(str(tmp_path / "seg")))
+    assert len(pngs) == num_ex * interval and pngs[0].startswith("seg_frankfurt_000000_000017")
+    seg = np.asarray(Image.open(str(tmp_path / "seg" / "seg_lindau_000000_000019_leftImg8bit.png")))
+    gt = np.asarray(Image.open(str(tmp_path / "data" / "gtFine" / "val" / "lindau" / "lindau_000000_000019_gtFine_trainIds.png")))
+    assert seg.shape == gt.shape and float((seg != gt).mean()) < 1e-3          # the written palette PNG holds the label ids

@@ -447,9 +447,9 @@ def test_label_lookup_keeps_the_city():
     """Cityscapes val holds lindau_0000NN_000019 and munster_0000NN_000019 for the same NN: the ground-truth lookup of
     the demo must key on (city, sequence, frame), or every lindau frame is scored against a munster label."""
     from accel_amd import demo
-    files = ["/d/gtFine/val/lindau/lindau_000003_000019_gtFine_labelTrainIds.png",
-             "/d/gtFine/val/munster/munster_000003_000019_gtFine_labelTrainIds.png",
-             "/d/gtFine/val/frankfurt/frankfurt_000001_000019_gtFine_labelTrainIds.png"]
+    files = ["/d/gtFine/val/lindau/lindau_000003_000019_gtFine_trainIds.png",
+             "/d/gtFine/val/munster/munster_000003_000019_gtFine_trainIds.png",
+             "/d/gtFine/val/frankfurt/frankfurt_000001_000019_gtFine_trainIds.png"]
     table = {demo.label_key(f): f for f in files}
     assert len(table) == 3
     assert table[demo.label_key("/d/leftImg8bit_sequence/val/lindau/lindau_000003_000019_leftImg8bit.png")] == files[0]
