@@ -20,6 +20,13 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned of
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f32x3 buf_load3(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0));
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
