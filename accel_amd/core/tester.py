@@ -83,7 +83,8 @@ class Predictor(object):
         self._model = model
         self._arg_params = arg_params or {}
         self._aux_params = aux_params or {}
-        self._plans = {}      # (H, W) -> (role, runtime.Plan, Lowering)
+        self._plans = {}      # (N, H, W) -> (runtime.Plan, Lowering, runtime.Model)
+        self._variants = {}   # (N, H, W) -> ((plan, lowering) reading `feat`, (plan, lowering) reading `feat_b`)
         self._is_key = "feat_key" not in symbol.list_arguments() or "feat_key" in self.output_names \
             or any(n.startswith("res5c_relu") for n in self.output_names)
         shapes = dict(provide_data[0]) if provide_data else {}
@@ -145,9 +146,15 @@ class Predictor(object):
             model.set_params(self._arg_params, self._aux_params)
             model._params_token = token
         self._model = model
-        text, lw = _lower.lower(self._symbol, shapes, multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0",
-                                conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
-                                fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
+        # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
+        # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
+        pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
+        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
+                  fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
+        text, lw = _lower.lower(self._symbol, shapes, feat_slot=0 if pingpong else None, **kw)
+        pingpong = pingpong and any(getattr(getattr(v, "buf", None), "space", None) == "feat_b" for v in lw.outputs.values())
+        if not pingpong and lw.feat_slot is not None:
+            text, lw = _lower.lower(self._symbol, shapes, **kw)
         if lw.derived:
             done = getattr(model, "_derived_from", {})
             todo = {k: v for k, v in lw.derived.items() if done.get(k) != token}
@@ -163,6 +170,11 @@ class Predictor(object):
             role = "%s_%x" % (role, id(self) & 0xFFFFFF)
         plan = model.add_plan(role, text)
         plan.finalize()
+        if pingpong:
+            text_b, lw_b = _lower.lower(self._symbol, shapes, feat_slot=1, **kw)
+            plan_b = model.add_plan(role + "_b", text_b)      # `cur_b`: what accel_cur_forward runs on odd non-key frames
+            plan_b.finalize()
+            self._variants[(N, H, W)] = ((plan, lw), (plan_b, lw_b))
         self._plans[(N, H, W)] = (plan, lw, model)
         return self._plans[(N, H, W)]
 
@@ -203,13 +215,18 @@ class Predictor(object):
         if not self._is_key:
             fk = arrays["feat_key"]
             ref = getattr(fk, "device_ref", None)
-            if ref and ref[0] is m and ref[1] == "feat" and ref[2] == m.generation("feat"):
-                pass                                   # the handle IS the current content of the shared buffer
+            variants = self._variants.get((N, H, W))
+            if ref and ref[0] is m and ref[1] in ("feat", "feat_b") and ref[2] == m.generation(ref[1]) \
+                    and (ref[1] == "feat" or variants):
+                # the handle IS the current content of one of the model's feature buffers: run the plan that reads it
+                if variants:
+                    plan, lw = variants[1 if ref[1] == "feat_b" else 0]
             elif ref and not getattr(fk, "has_host_copy", True):
-                if ref[1] == "feat" and ref[0] is not m and ref[2] == ref[0].generation("feat") and ref[0].ctx.device_id == m.ctx.device_id:
+                if ref[1] in ("feat", "feat_b") and ref[0] is not m and ref[2] == ref[0].generation(ref[1]) \
+                        and ref[0].ctx.device_id == m.ctx.device_id:
                     # a handle of ANOTHER model on this GPU that is still current there: copy HBM to HBM
                     ref[0].ctx.sync()
-                    src, n = ref[0].buffer("feat")
+                    src, n = ref[0].buffer(ref[1])
                     m.write_device("feat", src, N * 2048 * (H // 16) * (W // 16) * 4)
                 else:
                     raise runtime.AccelError(
@@ -227,7 +244,7 @@ class Predictor(object):
             elif d == "logits":
                 out[name] = self._logits_handle(N, H, W)
             else:
-                out[name] = self._feat_handle(N, H, W)
+                out[name] = self._feat_handle(N, H, W, getattr(getattr(d, "buf", None), "space", "feat"))
         return [out]
 
     def _logits_handle(self, N, H, W, ncls=19):
@@ -241,21 +258,21 @@ class Predictor(object):
         return DeviceArray(shape=(N, ncls, H, W), fetch=lambda: m.read("logits", (N, ncls, H, W)),
                            device_ref=(m, "logits", m.generation("logits")), labels_of=labels)
 
-    def _feat_handle(self, N, H, W):
+    def _feat_handle(self, N, H, W, buf="feat"):
         m = self._model
         h, w = H // 16, W // 16
 
         def fetch():
-            nhwc = m.read("feat", (N, h, w, 2048))
+            nhwc = m.read(buf, (N, h, w, 2048))
             return np.ascontiguousarray(nhwc.transpose(0, 3, 1, 2))
-        gen = m.generation("feat")
+        gen = m.generation(buf)
 
         def fetch_checked():
-            if m.generation("feat") != gen:
+            if m.generation(buf) != gen:
                 raise runtime.AccelError("this feature handle is stale: its buffer has been written since (fetch it with "
                                          ".asnumpy() before the next forward that propagates a feature)")
             return fetch()
-        return DeviceArray(shape=(N, 2048, h, w), fetch=fetch_checked, device_ref=(m, "feat", gen))
+        return DeviceArray(shape=(N, 2048, h, w), fetch=fetch_checked, device_ref=(m, buf, gen))
 
     def _upload_feat(self, feat_nchw, N, H, W):
         f = np.asarray(feat_nchw, np.float32)
@@ -274,8 +291,12 @@ class Predictor(object):
         self._model.__dict__.setdefault("_prefetched", {})["data"] = data_array.uid
         return True
 
-    def plan_for(self, H, W, N=1):
+    def plan_for(self, H, W, N=1, slot=0):
+        """(plan, lowering) bound for N frames of H x W; slot 1 = the ping-pong variant of a non-key graph that reads
+        `feat_b` and writes `feat` (the one to run on every second non-key frame)."""
         plan, lw, _ = self._bind((H, W), N)
+        if slot and (N, H, W) in self._variants:
+            return self._variants[(N, H, W)][1]
         return plan, lw
 
 

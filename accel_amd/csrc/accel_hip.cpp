@@ -88,8 +88,13 @@ struct accel_model {
     std::map<std::string, uint64_t> generation;     // write generation per persistent buffer (accel_model_buffer_generation)
     struct Shadow { void* ptr = nullptr; size_t bytes = 0, filled = 0; hipEvent_t ready = nullptr, consumed = nullptr; bool was_consumed = false; };
     std::map<std::string, Shadow> shadows;          // prefetch targets (accel_model_prefetch / accel_model_commit)
+    // which buffer holds the current propagated feature: 0 = `feat`, 1 = `feat_b` (non-key graphs may be bound as a pair of
+    // plans `cur` / `cur_b` that ping-pong between the two instead of copying the warped feature back; whoever wrote last)
+    int feat_slot = 0;
     void source_written(const std::string& src) {
         ++generation[src];
+        if (src == "feat") feat_slot = 0;
+        else if (src == "feat_b") feat_slot = 1;
         for (auto& kv : derived_from) if (kv.second == src) derived_valid[kv.first] = false;
     }
 };
@@ -1424,7 +1429,7 @@ static int frame_outputs(accel_model* m, float* feat_out, float* logits_out, uin
     int rc;
     if (feat_out) {
         // `feat` lives NHWC in HBM; the boundary layout is NCHW (res5c_relu_output / warping_feat_output)
-        auto src = m->pbufs.find("feat");
+        auto src = m->pbufs.find(m->feat_slot ? "feat_b" : "feat");
         if (src == m->pbufs.end() || !m->feat_c) return fail(ACCEL_ERR_ARG, "feat_out requested but the model has no propagated feature");
         const size_t img = (size_t)m->feat_c * m->feat_h * m->feat_w;
         const size_t bytes = img * m->feat_n * sizeof(float);
@@ -1464,6 +1469,10 @@ extern "C" int accel_cur_forward(accel_model* m, const float* img_cur, const flo
     if (!m) return fail(ACCEL_ERR_ARG, "accel_cur_forward: NULL model");
     auto it = m->roles.find("cur");
     if (it == m->roles.end()) return fail(ACCEL_ERR_ARG, "accel_cur_forward: model has no 'cur' plan");
+    if (m->feat_slot == 1) {      // the current feature sits in `feat_b`: the plan that reads it
+        it = m->roles.find("cur_b");
+        if (it == m->roles.end()) return fail(ACCEL_ERR_ARG, "accel_cur_forward: the feature is in 'feat_b' but the model has no 'cur_b' plan");
+    }
     int rc;
     if (img_cur && (rc = accel_model_write(m, "data", img_cur, pbuf_bytes(m, "data"), img_on_device))) return rc;
     if (img_prev && (rc = accel_model_write(m, "data_key", img_prev, pbuf_bytes(m, "data_key"), img_on_device))) return rc;

@@ -82,9 +82,16 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True, fold_linear=True):
+    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True, fold_linear=True, feat_slot=None):
         self.sym = sym
         self.fold_linear = bool(fold_linear)
+        # Ping-pong of the propagated feature (non-key graphs): a warp cannot run in place, so the plan either warps into
+        # scratch and copies back (feat_slot None: two copies of 0.8 GB per call of 8 frames), or exists TWICE: variant 0
+        # reads `feat` / `featG` and writes `feat_b` / `featG_b`, variant 1 the other way round, and the host runs the
+        # variant whose source holds the current feature.  Key plans always write `feat` / `featG`.
+        self.feat_slot = feat_slot
+        self.feat_src = "feat_b" if feat_slot == 1 else "feat"
+        self.feat_dst = None if feat_slot is None else ("feat" if feat_slot == 1 else "feat_b")
         self.derived = {}      # derived parameter name -> ("deconv4x4s2*conv1x1", deconv weight, conv weight)
         self.derived_bufs = {} # derived persistent buffer -> {"from", "w", "cin", "cout", "H", "W"} (see lower_warp)
         self.shapes = infer_shapes(sym, input_shapes)
@@ -174,6 +181,9 @@ class Lowering(object):
     def _feat_image(self, conv, C, H, W):
         """The derived persistent buffer featG = W_conv * feat (no bias), kept in step with `feat` by the plans."""
         _, cin, _, _ = self.shape(conv.inputs[0])
+        if self.feat_slot == 1:
+            # the `_b` pair is only ever written by variant-0 plans, feature and image together: never stale
+            return self.pbuf_view("featG_b", C, H, W)
         v = self.pbuf_view("featG", C, H, W)
         self.derived_bufs["featG"] = {"from": "feat", "w": conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W, "N": self.N}
         return v
@@ -306,7 +316,7 @@ class Lowering(object):
         if node.op == "null":
             if node.name == "feat_key":
                 N, C, H, W = self.shape(node)
-                return self.pbuf_view("feat", C, H, W, N=N)
+                return self.pbuf_view(self.feat_src, C, H, W, N=N)
             raise NotImplementedError("variable %s used as activation" % node.name)
         if node.op == "_split_out":       # batch slice of an activation (accel_101.py:47-49)
             parent = self.input_view(node.inputs[0])
@@ -582,15 +592,19 @@ class Lowering(object):
             flow = flow.image(sl.attrs["index"] * per, per)
             self.absorbed.add(id(sl))
         fin = self.input_view(feat)
-        out = self.dest_for(B)
         nb, C, H, W = self.shape(B)
+        pingpong = self.feat_dst is not None and id(B) in self.head_ids and feat.op == "null" and feat.name == "feat_key" \
+            and id(B) not in self.concat_slot
+        out = self.pbuf_view(self.feat_dst, C, H, W, N=nb) if pingpong else self.dest_for(B)
         if flow.nimg != fin.nimg:
             raise NotImplementedError("warp %s: %d feature images vs %d flow fields" % (B.name, fin.nimg, flow.nimg))
         self.emit("warp", {"name": B.name, "feat": fin, "flow": flow, "out": out}, [fin, flow], [out],
                   nbytes=2.0 * 4 * C * H * W + 8.0 * H * W, n=nb)
         self.absorbed.update((id(B), id(grid)))
         self.val[id(B)] = out
-        if id(B) in self.head_ids:
+        if pingpong:
+            self.outputs[B.name + "_output"] = out      # the propagated feature of the next frame, where the warp wrote it
+        elif id(B) in self.head_ids:
             # the propagated feature: becomes `feat` for the next frame (demo.py:241-243)
             dst = self.pbuf_view("feat", C, H, W, N=nb)
             self.emit("copy", {"src": out, "dst": dst}, [out], [dst], nbytes=8.0 * C * H * W, n=nb)
@@ -608,13 +622,15 @@ class Lowering(object):
             relu = self._head_on_feature(conv, B)
             _, Cg, _, _ = self.shape(conv)
             g_in = self._feat_image(conv, Cg, H, W)
-            g_out = View(self.new_buf(Cg, H, W), Cg)
+            g_out = self.pbuf_view("featG" if self.feat_slot == 1 else "featG_b", Cg, H, W) if pingpong \
+                else View(self.new_buf(Cg, H, W), Cg)
             act_out = self.dest_for(relu)
             self.emit("warp", {"name": B.name + "*" + conv.name, "feat": g_in, "flow": flow, "out": g_out, "out2": act_out,
                                "bias": conv.inputs[2].name}, [g_in, flow], [g_out, act_out],
                       nbytes=3.0 * 4 * Cg * H * W + 8.0 * H * W)
-            g_dst = self.pbuf_view("featG", Cg, H, W)
-            self.emit("copy", {"src": g_out, "dst": g_dst}, [g_out], [g_dst], nbytes=8.0 * Cg * H * W)
+            if not pingpong:
+                g_dst = self.pbuf_view("featG", Cg, H, W)
+                self.emit("copy", {"src": g_out, "dst": g_dst}, [g_out], [g_dst], nbytes=8.0 * Cg * H * W)
             self.absorbed.update((id(conv), id(relu)))
             self.val[id(conv)] = act_out
             self.val[id(relu)] = act_out
@@ -824,6 +840,6 @@ def init_plan_text(name, d):
                                            d["from"], cin, _r4(cin), H, W, sfx, 2.0 * N * H * W * cin * cout)]) + "\n"
 
 
-def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True):
-    lw = Lowering(sym, input_shapes, multi_stream=multi_stream, fold_linear=fold_linear).run()
+def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True, feat_slot=None):
+    lw = Lowering(sym, input_shapes, multi_stream=multi_stream, fold_linear=fold_linear, feat_slot=feat_slot).run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

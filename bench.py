@@ -125,6 +125,7 @@ class Workload(object):
                                       model=self.model, batch=B)
         self.key, _ = self.runner.key_predictor.plan_for(H, W, B)
         self.cur, _ = self.runner.cur_predictor.plan_for(H, W, B)
+        self.cur_b, _ = self.runner.cur_predictor.plan_for(H, W, B, slot=1)     # ping-pong partner (the same plan if unpaired)
         # B clips, distinct per rank and clip: frames[t] = frame t of every clip, (B, 3, H, W) fp32, mean-subtracted
         clips = [synth.make_clip(H, W, interval, seed=20260929 + rank * 64 + b) for b in range(B)]
         self.host_frames = [np.concatenate([image.transform(c[t], config.network.PIXEL_MEANS).astype(np.float32) for c in clips], axis=0)
@@ -142,7 +143,7 @@ class Workload(object):
                 self.key.run()
             else:
                 m.write_device("data_key", self.dev_frames[t - 1].data_ptr(), self.nbytes)
-                self.cur.run()
+                (self.cur if t % 2 else self.cur_b).run()      # frame 1 reads the key plan's `feat`, frame 2 `feat_b`, ...
             if self.gather is not None:
                 self.gather.submit()
 

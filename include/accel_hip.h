@@ -126,7 +126,11 @@ int accel_model_read_async(accel_model* m, const char* buf, void* pinned_dst, si
  * (demo.py:235-245; tester.py:158-171 im_segment).  img_*: fp32 1x3xHxW already
  * mean-subtracted (lib/utils/image.py:224-235).  Any output pointer may be NULL.
  * feat_out / logits_out are NCHW fp32, labels_out uint8 HxW (first-max argmax).
- * The propagated feature stays in HBM between calls. */
+ * The propagated feature stays in HBM between calls: in persistent buffer
+ * `feat`, or -- when the non-key graph was bound as the plan pair `cur` /
+ * `cur_b` (accel_amd/lower.py, feat_slot) -- alternately in `feat` and
+ * `feat_b`; accel_cur_forward runs the plan that reads the buffer written
+ * last, so callers never see the difference.  A host upload goes to `feat`. */
 int accel_key_forward(accel_model* m, const float* img, int img_on_device,
                       float* feat_out, float* logits_out, uint8_t* labels_out, int out_on_device);
 int accel_cur_forward(accel_model* m, const float* img_cur, const float* img_prev, int img_on_device,

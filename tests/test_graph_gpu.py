@@ -353,9 +353,10 @@ def test_pinned_prefetch_pipeline_is_invisible(demo_cfg):
 
 
 def test_stale_feature_handle_is_never_read_silently(demo_cfg):
-    """A feature handle is valid until the next forward that writes the propagated feature.  Reusing an older handle
-    (DFF-style: the key feature for several non-key frames) must either use the handle's host copy or fail -- and two
-    runners interleaving clips of the same size must not see each other's feature."""
+    """A feature handle is valid until the next forward that writes ITS buffer (non-key plans ping-pong between `feat`
+    and `feat_b`, so the key feature survives one non-key frame and is overwritten by the second).  Reusing an older
+    handle (DFF-style: the key feature for several non-key frames) must either still be valid, use the handle's host
+    copy, or fail -- and two runners interleaving clips of the same size must not see each other's feature."""
     from accel_amd import demo, runtime
     from accel_amd.core import tester
     H, W = 128, 256
@@ -366,10 +367,21 @@ def test_stale_feature_handle_is_never_read_silently(demo_cfg):
     try:
         r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
         ref = [r.step(i, A[i], 3)[0].asnumpy().copy() for i in range(3)]
+        # (0) after ONE non-key frame the key feature is still in `feat` (the warp went to `feat_b`): reuse is legal and
+        #     equals uploading a host copy of the key feature
+        r.step(0, A[0], 3)
+        key_feat = r.feat
+        assert key_feat.device_ref[1] == "feat"
+        r.step(1, A[1], 3)
+        assert r.feat.device_ref[1] == "feat_b"
+        r.feat = key_feat
+        reuse = r.step(2, A[2], 3)[0].asnumpy().copy()
         # (1) stale handle without a host copy: refused
         r.step(0, A[0], 3)
         key_feat = r.feat
-        r.step(1, A[1], 3)                      # warps `feat` in place: key_feat no longer describes the buffer
+        r.step(1, A[1], 3)                      # feat -> feat_b
+        r.step(2, A[2], 3)                      # feat_b -> feat: key_feat no longer describes the buffer
+        assert r.feat.device_ref[1] == "feat"
         r.feat = key_feat
         with pytest.raises(runtime.AccelError, match="overwritten"):
             r.step(2, A[2], 3)
@@ -387,6 +399,7 @@ def test_stale_feature_handle_is_never_read_silently(demo_cfg):
         r.feat = mx.nd.array(key_host)
         expect = r.step(2, A[2], 3)[0].asnumpy()
         np.testing.assert_allclose(dff_style, expect, rtol=0, atol=1e-5 * max(1.0, float(np.abs(expect).max())))
+        np.testing.assert_allclose(reuse, expect, rtol=0, atol=1e-5 * max(1.0, float(np.abs(expect).max())))
         # (3) two runners, same size and weights, clips interleaved frame by frame
         r2 = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
         refB = [r2.step(i, B[i], 3)[0].asnumpy().copy() for i in range(3)]

@@ -197,6 +197,38 @@ def test_plan_is_well_formed(demo_cfg, version, key):
     assert "Concat" not in text and all(k in ("prep_rgb", "prep_flow", "conv", "pool", "warp", "dcn_cols", "score_tail", "copy") for k in kinds)
 
 
+@pytest.mark.parametrize("version", ["18", "50"])
+def test_feature_pingpong_variants(demo_cfg, version):
+    """Non-key graphs bind as two plans that hand the propagated feature back and forth between `feat`/`featG` and
+    `feat_b`/`featG_b`: no copy-back of the warped feature, same work otherwise (accel_18.py:174-175 + demo.py:241-243)."""
+    tb, base = _plan(version, False)
+    (t0, v0), (t1, v1) = _plan(version, False, feat_slot=0), _plan(version, False, feat_slot=1)
+    kinds = lambda lw: [k for k, _ in lw.ops]
+    assert kinds(base).count("copy") == 2 and kinds(v0).count("copy") == 0 and kinds(v1).count("copy") == 0
+    assert [k for k in kinds(base) if k != "copy"] == kinds(v0) == kinds(v1)
+    assert v0.total_flops == v1.total_flops == base.total_flops
+    pb = lambda t: set(re.findall(r"^pbuf name=(\S+)", t, re.M))
+    assert pb(t0) == pb(t1) == pb(tb) | {"feat_b", "featG_b"}
+    warps = lambda t: [dict(x.split("=", 1) for x in l.split()[1:]) for l in t.splitlines() if l.startswith("warp ")]
+    w0, w1 = warps(t0), warps(t1)
+    assert w0[0]["feat"].startswith("feat:") and w0[0]["out"].startswith("feat_b:")
+    assert w1[0]["feat"].startswith("feat_b:") and w1[0]["out"].startswith("feat:")
+    assert w0[1]["feat"].startswith("featG:") and w0[1]["out"].startswith("featG_b:")
+    assert w1[1]["feat"].startswith("featG_b:") and w1[1]["out"].startswith("featG:")
+    assert v0.outputs["warping_feat_output"].buf.space == "feat_b" and v1.outputs["warping_feat_output"].buf.space == "feat"
+    # only `featG` is a derived buffer (rebuilt from `feat` after a host upload); the `_b` pair is written by plans only
+    assert re.search(r"^pbuf name=featG bytes=\d+ from=feat$", t0, re.M) and "from=feat_b" not in t0 + t1
+    # the key graph is not affected by the option
+    assert _plan(version, True, feat_slot=0)[0] == _plan(version, True)[0]
+
+
+def test_feature_pingpong_falls_back_for_feature_fusion(demo_cfg):
+    """Accel-101 warps straight into the Concat in front of its fusion convolution (accel_101.py:161-166): the warped
+    feature is a slice of that buffer, so the plan keeps its one copy-back and the propagated feature stays in `feat`."""
+    _, v0 = _plan("101", False, feat_slot=0)
+    assert [k for k, _ in v0.ops].count("copy") == 1 and v0.outputs["warping_feat_output"].buf.space == "feat"
+
+
 def test_fusion_of_the_preactivation_units(demo_cfg):
     _, lw = _plan("18", False)
     convs = {a["name"]: a for k, a in lw.ops if k == "conv"}
