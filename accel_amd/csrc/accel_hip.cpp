@@ -508,6 +508,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.y = op.b.ptr; c.yCs = op.b.Cs;
     if (op.d.set) { c.res = op.d.ptr; c.resCs = op.d.Cs; }
     c.Cout_store = cout_store;
+    c.Cout = cout;
     // batch: the GEMM M dimension runs over (n, oy, ox); images are stacked pixel-major in every view
     if (op.b.N != op.a.N || (op.c.set && op.c.N != op.a.N) || (op.d.set && op.d.N != op.a.N))
         return fail(ACCEL_ERR_PLAN, "conv %s: batch sizes of the views differ", op.name.c_str());

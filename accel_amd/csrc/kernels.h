@@ -20,6 +20,7 @@ struct ConvParams {
     int kh, kw, sh, sw, ph, pw, dh, dw;
     int K_pad;             // flattened K (kh*kw*Cin) rounded up to 32
     int Cout_store;        // channels written (pad channels get exact zeros)
+    int Cout;              // real output channels (<= Cout_store; the rows beyond it in the packed weights are zero)
     int yCs, y2Cs, resCs;
     int M;                 // N*Ho*Wo
     int act;               // 0 none, 1 relu, 2 leaky

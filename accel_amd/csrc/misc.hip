@@ -563,8 +563,97 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
     }
 }
 
+// The same layer for its common shape -- 3x3, stride 1, pad 1, at most 2 real output channels (every flow predictor of
+// FlowNet-S, resnet_v1_101_flownet_deeplab.py:1776-1801) -- with the input reuse the one-pixel-per-wavefront kernel
+// lacks: a wavefront owns a strip of TX consecutive output pixels of one row; lanes split the channels (one float4 per
+// lane and pass); per kernel row it loads the TX + 2 input pixels once and uses each for up to 3 output pixels, and the
+// 6 weight quads of the row for all TX pixels: 12 FMAs per 16-byte load instead of 3, every input pixel fetched
+// 3 x (TX+2)/TX times through the L2 instead of 9, no work for the two zero padding rows of the weight matrix.
+template <int TX>
+__global__ __launch_bounds__(256) void conv_narrow3x3_kernel(ConvParams p, int strips)
+{
+    const int lane = threadIdx.x & 63;
+    // the 4 wavefronts of a block take the SAME strip of 4 consecutive rows: the rows they share (each input row feeds
+    // 3 output rows) are then fetched by one CU / one XCD's L2 instead of three different ones
+    const int rows = p.M / p.Wo;                 // N * Ho
+    const int rgrp = blockIdx.x / strips;
+    const int row = rgrp * 4 + (threadIdx.x >> 6), ox0 = (blockIdx.x - rgrp * strips) * TX;
+    if (row >= rows) return;
+    const int n = row / p.Ho, oy = row - n * p.Ho;
+    const float* xn = p.x + (size_t)n * p.H * p.W * p.xCs;
+    const int C4 = p.Cin / 4;
+    const size_t rs = (size_t)p.K_pad / 4;       // float4s per weight row
+    float acc[TX][2];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) acc[t][0] = acc[t][1] = 0.f;
+    for (int c = lane; c < C4; c += 64) {
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)p.H) continue;       // wave-uniform
+            const float* xrow = xn + (size_t)iy * p.W * p.xCs;
+            float4 x[TX + 2];
+#pragma unroll
+            for (int i = 0; i < TX + 2; ++i) {
+                const int ix = ox0 - 1 + i;                    // wave-uniform as well
+                x[i] = (unsigned)ix < (unsigned)p.W ? reinterpret_cast<const float4*>(xrow + (size_t)ix * p.xCs)[c]
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float4* wp = reinterpret_cast<const float4*>(p.w + (size_t)(ky * 3) * p.Cin) + c;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 w0 = wp[(size_t)kx * C4], w1 = wp[rs + (size_t)kx * C4];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    const float4 v = x[t + kx];
+                    acc[t][0] += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+                    acc[t][1] += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TX; ++t)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc[t][0] += __shfl_xor(acc[t][0], o);
+            acc[t][1] += __shfl_xor(acc[t][1], o);
+        }
+    if (lane < TX && ox0 + lane < p.Wo) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < TX; ++t) if (lane == t) { a0 = acc[t][0]; a1 = acc[t][1]; }
+        const size_t m = (size_t)row * p.Wo + ox0 + lane;
+        float v[4] = {a0, a1, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = v[e] * p.scale[e] + p.shift[e];
+            if (p.res) v[e] += p.res[m * p.resCs + e];
+            if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+            else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        *reinterpret_cast<float4*>(p.y + m * p.yCs) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st)
 {
+    if (p.kh == 3 && p.kw == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 && p.ph == 1 && p.pw == 1 &&
+        p.Cout <= 2 && p.Ho == p.H && p.Wo == p.W && p.Cin % 4 == 0) {
+        // strips of 8 pixels once the map is big enough to fill the chip with them (4 wavefronts per block), of 4 below
+        // that; maps too small even for those keep the one-pixel-per-wavefront kernel (more wavefronts)
+        const int rows = p.M / p.Wo;
+        if ((long)p.M >= 8L * 4 * 1024) {
+            const int strips = cdiv(p.Wo, 8);
+            hipLaunchKernelGGL(conv_narrow3x3_kernel<8>, dim3(cdiv(rows, 4) * strips), dim3(256), 0, st, p, strips);
+            return hipGetLastError();
+        }
+        if ((long)p.M >= 4L * 4 * 512) {
+            const int strips = cdiv(p.Wo, 4);
+            hipLaunchKernelGGL(conv_narrow3x3_kernel<4>, dim3(cdiv(rows, 4) * strips), dim3(256), 0, st, p, strips);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(conv_narrow_kernel, dim3(cdiv(p.M, 4)), dim3(256), 0, st, p);
     return hipGetLastError();
 }

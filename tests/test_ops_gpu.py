@@ -215,6 +215,23 @@ def test_conv2d_batched_split_k_and_narrow(ctx):
     close(ctx.conv2d(x2, w2, b2, 1, 1, 1), O.conv2d(x2, w2, b2, 1, 1, 1))
 
 
+@pytest.mark.parametrize("N,C,K,H,W", [
+    (1, 388, 2, 13, 21),        # strips of 4 with a ragged last strip, two channel passes (97 quads)
+    (2, 196, 2, 64, 128),       # big enough for strips of 8
+    (3, 1028, 2, 40, 100),      # strips of 8, width not a multiple of 8, 5 channel passes
+    (2, 772, 1, 9, 7),          # one real output channel, map narrower than a strip
+    (1, 40, 2, 3, 3),           # fewer channel quads than lanes
+])
+def test_flow_predictor_strip_kernel(ctx, N, C, K, H, W):
+    """3x3 / stride 1 / pad 1 convolutions with <= 2 output channels take the strip kernel (conv_narrow3x3_kernel):
+    borders on every side, ragged strips, batch, and the fused epilogue."""
+    x, w, b = rnd(90, N, C, H, W), rnd(91, K, C, 3, 3, scale=(2.0 / (9 * C)) ** 0.5), rnd(92, K)
+    close(ctx.conv2d(x, w, b, 1, 1, 1), O.conv2d(x, w, b, 1, 1, 1))
+    scale, shift, res = rnd(93, K), rnd(94, K), rnd(95, N, K, H, W)
+    ref = O.conv2d(x, w, None, 1, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=2, slope=0.1), O.leaky_relu(ref, 0.1))
+
+
 def test_deconv_deform_pool_batched(ctx):
     x, w = rnd(80, 2, 36, 6, 9), rnd(81, 36, 24, 4, 4, scale=0.1)
     close(ctx.deconv2d_4x4s2(x, w), O.deconv2d(x, w, None, stride=2, pad=1))
