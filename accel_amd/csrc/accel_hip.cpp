@@ -584,6 +584,23 @@ static int finalize_conv(accel_plan* p, Op& op)
                                        "output channels only", op.name.c_str());
         }
     }
+    {
+        // weight-stationary streaming kernel for the 1x1 expand layers with K = 64 / 128 (ACCEL_WS1X1=0 withholds it)
+        const char* se = getenv("ACCEL_WS1X1");
+        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_WS;
+        c.y2 = op.c.set ? op.c.ptr : nullptr;
+        if (want && !cols && cin == cin_pad && conv_ws_eligible(c)) {
+            std::vector<float> ww(conv_ws_pack_floats(cin, cout_store), 0.f);
+            conv_ws_pack(w->data.data(), cout, cin, cout_store, ww.data());
+            void* dw = nullptr;
+            if ((rc = dev_upload(p, ww.data(), ww.size() * sizeof(float), &dw))) return rc;
+            c.wws = static_cast<const float*>(dw);
+            c.wws_bytes = (unsigned)(ww.size() * sizeof(float));
+        } else if (c.force_tile == CONV_TILE_WS) {
+            return fail(ACCEL_ERR_ARG, "conv %s: the weight-stationary kernel takes 1x1 / stride 1 layers from 64 to a multiple of 256 "
+                                       "or from 128 to a multiple of 128 channels (ReLU or no activation, one output) only", op.name.c_str());
+        }
+    }
     c.narrow = (cout_store == 4 && !c.deconv2x && !op.c.set && c.force_tile < 0 && kv_int(kv, "narrow", 1)) ? 1 : 0;
     c.no_split = (int)kv_int(kv, "nosplit", 0);
     c.split_target = 0;
@@ -850,7 +867,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-3"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-4"
 
 static std::string lib_dir()
 {
@@ -959,6 +976,7 @@ static int autotune_plan(accel_plan* p)
                 if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
             }
             if (c.wstem) cs.push_back({CONV_TILE_STEM, 0, 0});
+            if (c.wws) cs.push_back({CONV_TILE_WS, 0, 0});
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
@@ -998,7 +1016,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

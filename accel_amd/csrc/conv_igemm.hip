@@ -930,7 +930,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if (tile >= 20 && tile <= 30) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM;
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS;
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
@@ -951,7 +951,7 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
-    if (tile == CONV_TILE_STEM) return 0;
+    if (tile == CONV_TILE_STEM || tile == CONV_TILE_WS) return 0;
     if (tile == CONV_TILE_WINO) {
         // Winograd blocks own 64 tiles (256 pixels) x 64 channels; the K loop runs in steps of 8 channels, unrolled by 2.
         // Splitting it over blockIdx.y leaves raw partial OUTPUTS (the output transform is linear) that the ordinary
@@ -994,6 +994,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.narrow) return launch_conv_narrow(p, st);
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
+    if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
     if (p.f16) {      // fp16-MFMA path: geometry ids 0-4 / 10-12 map onto the same tile shapes
         switch (conv_pick_tile(p)) {
             case 0: case 5: return launch_f16<128, 128, 2, 2>(p, st);

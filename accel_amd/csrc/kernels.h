@@ -47,6 +47,9 @@ struct ConvParams {
     int wino_T;            // 2x2 output tiles = M / 4, filled by the launcher
     // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
     const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
+    // weight-stationary streaming 1x1 variant (conv_1x1ws.hip, tile id 60): weights as the LDS image per column group
+    const float* wws;      // null: not a 64 -> k*256 / 128 -> k*128 1x1 stride-1 layer (or ACCEL_WS1X1=0)
+    unsigned wws_bytes;
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
@@ -64,6 +67,11 @@ bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
+#define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)
+bool conv_ws_eligible(const ConvParams& p);
+size_t conv_ws_pack_floats(int Cin, int cout_store);
+void conv_ws_pack(const float* w, int Cout, int Cin, int cout_store, float* out);
+hipError_t launch_conv_ws(const ConvParams& p, hipStream_t st);
 size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns workspace bytes
 
 // ---- bandwidth-bound kernels (misc.hip) ---------------------------------------

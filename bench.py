@@ -211,7 +211,7 @@ class Workload(object):
                     ms += wgt * float(d)
                     n += wgt
                     name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_f32_kernel" if op["tile"] == 40
-                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv_igemm_f16_kernel" if dtype != "f32" else "conv_igemm_f32_kernel")
+                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv1x1_ws_kernel" if op["tile"] == 60 else "conv_igemm_f16_kernel" if dtype != "f32" else "conv_igemm_f32_kernel")
                     f = fam.setdefault(name, [0.0, 0.0, 0.0])
                     f[0] += wgt; f[1] += wgt * float(d); f[2] += wgt * op["flops"]
         clip_ms = float(kms.sum()) + (self.interval - 1) * float(cms.sum())
@@ -225,7 +225,7 @@ class Workload(object):
                                                         "executed rate = algorithmic / 2.25")
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "traffic_note": None, "algorithmic_bytes_per_launch": round(by / n),
-                "kernel": "convolution kernels of the path (implicit GEMM + Winograd F(2x2,3x3) + 7x7 stem + narrow-N), per family below",
+                "kernel": "convolution kernels of the path (implicit GEMM + Winograd F(2x2,3x3) + 7x7 stem + weight-stationary 1x1 + narrow-N), per family below",
                 "achieved_note": "ALGORITHMIC flops (2 x MAC of the direct convolution after the two exact linear folds of DESIGN.md 4) of all conv "
                                  "launches of one step / the sum of their HIP-event durations",
                 "families": families, "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2),

@@ -63,7 +63,7 @@ def main():
 
 
     if len(sys.argv) > 5:
-        fams = ("conv_igemm_f32_kernel", "conv_wino_f32_kernel", "conv_stem_f32_kernel", "conv_narrow_kernel", "conv_igemm_f16_kernel")
+        fams = ("conv_igemm_f32_kernel", "conv_wino_f32_kernel", "conv_stem_f32_kernel", "conv1x1_ws_kernel", "conv_narrow_kernel", "conv_narrow3x3_kernel", "conv_igemm_f16_kernel")
         fam = "convolution kernels: " + ", ".join(fams)
         is_conv = lambda k: any(f in k for f in fams)
         rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if is_conv(k)) * 2 * 1024

@@ -349,3 +349,33 @@ def test_conv2d_stem_kernel_rejects_other_layers(ctx):
         ctx.conv2d(rnd(85, 1, 6, 32, 32), rnd(86, 64, 6, 7, 7), None, 2, 3, 1, tile=50)       # FlowNet's 6-channel stem
     with pytest.raises(AccelError, match="stem kernel"):
         ctx.conv2d(rnd(87, 1, 3, 32, 32), rnd(88, 32, 3, 7, 7), None, 2, 3, 1, tile=50)       # 32 output channels
+
+
+# ---- weight-stationary streaming 1x1 kernel (launch geometry id 60, conv_1x1ws.hip) --------------------------------------
+@pytest.mark.parametrize("N,C,K,H,W", [
+    (1, 64, 256, 32, 48),        # res2 branch1 / branch2c shape class: 12 pixel tiles of 128, fewer tiles than CUs
+    (2, 64, 256, 37, 53),        # ragged last pixel tile, batch
+    (1, 64, 512, 24, 40),        # two column groups of 256 channels
+    (1, 128, 512, 40, 72),       # res3 branch2c class: pixel tiles of 64, four column groups of 128
+    (3, 128, 128, 19, 23),       # one column group, ragged
+    (1, 64, 256, 160, 288),      # more pixel tiles than persistent blocks: every block streams several
+])
+def test_conv2d_weight_stationary_1x1_matches_oracle(ctx, N, C, K, H, W):
+    x, w, b = rnd(100, N, C, H, W), rnd(101, K, C, 1, 1, scale=(2.0 / C) ** 0.5), rnd(102, K)
+    close(ctx.conv2d(x, w, b, 1, 0, 1, tile=60), O.conv2d(x, w, b, 1, 0, 1))
+    scale, shift, res = rnd(103, K), rnd(104, K), rnd(105, N, K, H, W)
+    ref = O.conv2d(x, w, None, 1, 0, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res
+    close(ctx.conv2d(x, w, None, 1, 0, 1, scale=scale, shift=shift, residual=res, act=1, tile=60), O.relu(ref))
+    close(ctx.conv2d(x, w, None, 1, 0, 1, scale=scale, shift=shift, residual=res, tile=60), ref)
+
+
+def test_conv2d_weight_stationary_rejects_other_layers(ctx):
+    from accel_amd.runtime import AccelError
+    for args in ((rnd(106, 1, 256, 8, 8), rnd(107, 64, 256, 1, 1), 1, 0),        # K = 256
+                 (rnd(108, 1, 64, 8, 8), rnd(109, 128, 64, 1, 1), 1, 0),         # 128 output channels from 64
+                 (rnd(110, 1, 64, 8, 8), rnd(111, 256, 64, 1, 1), 2, 0),         # stride 2
+                 (rnd(112, 1, 64, 8, 8), rnd(113, 256, 64, 3, 3), 1, 1)):        # 3x3
+        with pytest.raises(AccelError, match="weight-stationary"):
+            ctx.conv2d(args[0], args[1], None, args[2], args[3], 1, tile=60)
+    with pytest.raises(AccelError, match="weight-stationary"):
+        ctx.conv2d(rnd(114, 1, 64, 8, 8), rnd(115, 256, 64, 1, 1), None, 1, 0, 1, act=2, slope=0.1, tile=60)     # leaky ReLU
