@@ -145,6 +145,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
         if (c == 3) *reinterpret_cast<f32x4*>(Vs + buf * VSTAGE + v_dst + i * 4 * VPS) = vo;
     };
     auto wait_all_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wait_dma_barrier = [&]() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // all but the 4 youngest (patch loads)
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -197,8 +198,10 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                 acc[pp][sI] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[c][kg], av, acc[pp][sI], 0, 0, 0);
                 if (PIPE) {
                     const int slot = pp * 4 + r;
-                    if (slot < NL) load_ring(k + 2, K2, slot);
-                    else if (slot >= NL && slot < NL + 4) issue_u_one(k + 1, cur ^ 1, slot - NL);
+                    // weight DMAs first, patch loads behind them: the barrier at the end of the step then waits for the DMAs
+                    // only (vmcnt(NL): the counter retires in order) and the patch loads keep their 1.5 steps of lead
+                    if (slot < 4) issue_u_one(k + 1, cur ^ 1, slot);
+                    else if (slot < 4 + NL) load_ring(k + 2, K2, slot - 4);
                     else if (slot >= 32 && slot < 48) transform_one(cur ^ 1, K2 ^ 1, slot - 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
 #define WINO_STEP(s, pipe_t)                                                   \
     do {                                                                       \
         kstep(k + (s), std::integral_constant<int, (s)>(), pipe_t());          \
-        if (pipe_t::value) wait_all_barrier();                                 \
+        if (pipe_t::value) wait_dma_barrier();                                 \
     } while (0)
     int k = 0;
     for (; k + 2 < nk; k += 2) {
