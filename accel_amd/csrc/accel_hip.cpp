@@ -149,7 +149,7 @@ struct accel_plan {
     bool finalized = false;
     bool allow_graph = true;
     bool allow_tune = true;
-    bool f16 = false;               // option dtype=f16: convolutions on the fp16 matrix cores
+    int f16 = 0;                    // option dtype=f16: convolutions on the fp16 matrix cores; dtype=bf16x3: 2 (kernels.h)
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of one stream (stream-ordered)
     float* ws = nullptr;
     float* ws1 = nullptr;
@@ -267,7 +267,7 @@ static int parse_plan(accel_plan* p, const char* text)
         if (kind == "option") {
             if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0;
             if (kv_has(kv, "tune")) p->allow_tune = kv_int(kv, "tune", 1) != 0;
-            if (kv_has(kv, "dtype")) p->f16 = kv_str(kv, "dtype") == "f16";
+            if (kv_has(kv, "dtype")) p->f16 = kv_str(kv, "dtype") == "f16" ? 1 : kv_str(kv, "dtype") == "bf16x3" ? 2 : 0;
             continue;
         }
         if (kind == "meta") {
@@ -452,15 +452,60 @@ static int finalize_conv(accel_plan* p, Op& op)
     packed.resize(packed.size() + 256, 0.f);   // slack: the pipelined kernel prefetches up to two K steps past the end
     // fp16-MFMA mode (plan option dtype=f16): only where a K chunk of 8 never straddles two taps
     const char* env_dt = getenv("ACCEL_CONV_DTYPE");   // "f16": also for the single-operator entry points
-    const int want_f16 = (int)kv_int(kv, "f16", (p->f16 || (env_dt && !strcmp(env_dt, "f16"))) ? 1 : 0);
-    c.f16 = (want_f16 && c.Cin % 8 == 0 && cout_store > 4) ? 1 : 0;
+    const int dflt = (p->f16 == 2 || (env_dt && !strcmp(env_dt, "bf16x3"))) ? 2 : (p->f16 || (env_dt && !strcmp(env_dt, "f16"))) ? 1 : 0;
+    const int want_f16 = (int)kv_int(kv, "f16", dflt);
+    c.f16 = (want_f16 && c.Cin % 8 == 0 && cout_store > 4) ? want_f16 : 0;
     void* dw_ = nullptr;
-    if (c.f16) {
+    if (c.f16 == 2) {
+        // exact three-way split of every weight into bf16 terms (top 16 bits, then of the residual, twice): planes [3][packed]
+        const size_t n = packed.size();
+        std::vector<uint16_t> pb(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+            float r = packed[i];
+            for (int pl = 0; pl < 3; ++pl) {
+                uint32_t u; memcpy(&u, &r, 4);
+                u &= 0xFFFF0000u;
+                pb[pl * n + i] = (uint16_t)(u >> 16);
+                float t; memcpy(&t, &u, 4);
+                r -= t;
+            }
+        }
+        if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &dw_))) return rc;
+        c.w_plane = n;
+    } else if (c.f16) {
         std::vector<_Float16> ph(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
         if ((rc = dev_upload(p, ph.data(), ph.size() * sizeof(_Float16), &dw_))) return rc;
     } else if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
     c.w = static_cast<const float*>(dw_);
+    {
+        // fp32 layers also get their weights as three bf16 planes: the bf16x3 kernel (conv_igemm.hip) is then one more
+        // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_BF16X3=0 withholds it)
+        const char* be = getenv("ACCEL_BF16X3");
+        const int ft = (int)kv_int(kv, "tile", -1);
+        const bool forced = ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 5;
+        if (!c.f16 && c.Cin % 8 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
+            const size_t n = packed.size();
+            std::vector<uint16_t> pb(3 * n);
+            for (size_t i = 0; i < n; ++i) {
+                float r = packed[i];
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t u; memcpy(&u, &r, 4);
+                    u &= 0xFFFF0000u;
+                    pb[pl * n + i] = (uint16_t)(u >> 16);
+                    float t; memcpy(&t, &u, 4);
+                    r -= t;
+                }
+            }
+            void* d3 = nullptr;
+            if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
+            c.wb3 = d3;
+            c.w_plane = n;
+        } else if (forced) {
+            return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with input channels in multiples of 8 and more than "
+                                       "4 output channels only", op.name.c_str());
+        }
+    }
 
     // epilogue scale / shift
     std::vector<float> scale(rows, 0.f), shift(rows, 0.f);
@@ -525,7 +570,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     if (op.d.set) c.res_bytes = extent(op.d, cout_store);
     c.act = (int)kv_int(kv, "act", 0);
     c.slope = (float)kv_f(kv, "slope", 0.1);
-    c.w_bytes = (unsigned)((size_t)rows * c.K_pad * (c.f16 ? 2 : 4));
+    c.w_bytes = (unsigned)((size_t)rows * c.K_pad * (c.f16 ? 2 : 4));     // of one plane / class
     {
         // tap table, one entry per 4-wide K granule: (dy, dx, input byte offset relative to tap 0 / channel 0).
         // FAST shapes read it wave-uniformly through the scalar unit, the others per lane; padded K and the
@@ -977,10 +1022,13 @@ static int autotune_plan(accel_plan* p)
             }
             if (c.wstem) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wws) cs.push_back({CONV_TILE_WS, 0, 0});
-            static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35};
+            const int nb3 = c.wb3 ? 5 : 0;
+            static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
+                                        CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
-                if (nd && nd[0] == '1' && t >= 31) continue;   // A/B switch: leave the deep-prefetch variants out
+                if (t >= CONV_TILE_B3 && !nb3) continue;
+                if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 if (c.f16 && !(t <= 3 || t == 10)) continue;
                 cs.push_back({t, 0, 0});
@@ -1016,7 +1064,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * c.f16 + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

@@ -776,6 +776,180 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_f16_kernel(ConvPara
     conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 }
 
+// ---------------------------------------------------------------------------
+// fp32 on the bf16 matrix cores ("bf16x3", f16 == 2): every fp32 operand is split EXACTLY into three bf16 terms
+//     a = a0 + a1 + a2,   a0 = top 16 bits of a, a1 = top 16 bits of (a - a0), a2 = top 16 bits of (a - a0 - a1)
+// (8 significant bits each: 24 together, the residuals are exact in fp32), and a product is taken as the six terms
+//     a*b ~= a1*b1 + a0*b2 + a2*b0 + a0*b1 + a1*b0 + a0*b0          (the dropped terms are below 2^-23 |a*b|)
+// each an exact fp32 value (8 x 8 bits) accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the same accumulation the fp32
+// MFMA does, with a relative operand error of 2^-23 instead of rounding -- fp32-equivalent results (op-level error
+// against float64 is the same as the fp32 kernel's, tests/test_ops_gpu.py) from a pipe with 16x the fp32 MFMA rate,
+// at 6 products: 2.6x the fp32 matrix peak, and it leaves the vector ALUs (which the fp32 MFMA occupies) to the loader.
+// Weights are split on the host (three planes [3][rows][K_pad] of bf16), activations in the loader while they are staged
+// into LDS (three planes per tile).  Same tiles, addressing table, split-K and epilogue as the fp16 kernel.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& q0, unsigned& q1, unsigned& q2)
+{
+    const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
+    q0 = __builtin_amdgcn_perm(u1, u0, 0x07060302);                       // {top16(v1), top16(v0)}
+    const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), r1 = v1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    const unsigned s0 = __builtin_bit_cast(unsigned, r0), s1 = __builtin_bit_cast(unsigned, r1);
+    q1 = __builtin_amdgcn_perm(s1, s0, 0x07060302);
+    const float t0 = r0 - __builtin_bit_cast(float, s0 & 0xFFFF0000u), t1 = r1 - __builtin_bit_cast(float, s1 & 0xFFFF0000u);
+    q2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParams p, size_t wplane)
+{
+    constexpr int BK = 32, LDK = BK + 8;            // bf16 elements
+    constexpr int NTHR = 64 * WGM * WGN;
+    constexpr int CPR = BK / 8, RP = NTHR / CPR;    // 8-wide chunks per row, rows per pass
+    constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
+    constexpr int AR = BM / RP, BR = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
+    unsigned short* As = smem_b;                      // [3][BM][LDK]: ONE stage, two blocks per CU (see the loop)
+    unsigned short* Bs = smem_b + 3 * BM * LDK;       // [3][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nblk = p.MT * p.NT, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int nt = swz % p.NT, mt = swz / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    int ph = p.ph, pw = p.pw;
+    const unsigned short* wbase = reinterpret_cast<const unsigned short*>(p.w);
+    int py = 0, px = 0;
+    if (p.deconv2x) {
+        py = blockIdx.y >> 1; px = blockIdx.y & 1;
+        ph = 1 - py; pw = 1 - px;
+        wbase += (size_t)blockIdx.y * p.w_class_stride;
+    }
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    __amdgpu_buffer_rsrc_t wr_[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wr_[pl] = make_rsrc(wbase + pl * wplane, p.w_bytes);
+    const int HoWo = p.Ho * p.Wo;
+
+    const int srow = tid / CPR, scol = (tid % CPR) * 8;
+    int a_iy0[AR], a_ix0[AR], a_nb[AR];
+    unsigned b_off[BR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + RP * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo, rem = mm - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_iy0[i] = ok ? oy * p.sh - ph : -(1 << 28);
+        a_ix0[i] = ox * p.sw - pw;
+        a_nb[i] = n * p.H * p.W;
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 2);
+
+    const int KT_all = p.K_pad / BK;
+    const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
+    const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
+
+    f32x4 ralo[AR], rahi[AR];          // the activations travel as fp32 and are split when they are stored to LDS
+    i32x4 rb[BR][3];
+    const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
+    int4 tk_next = ktab[(kt_begin * BK + scol) / 4];
+    unsigned a_base[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
+    auto load_tiles = [&](int k0) {
+        const int4 tk = tk_next;                 // the lane's own 8-wide chunk = two 4-wide granules of one tap
+        tk_next = ktab[(k0 + BK + scol) / 4];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
+            ralo[i] = buf_load4(xr, off);
+            rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], k0 * 2, 0);
+    };
+    auto store_tiles = [&]() {
+        unsigned short* a = As;
+        unsigned short* b = Bs;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            i32x4 q[3];
+            unsigned x0, x1, x2;
+            split3_pair(ralo[i][0], ralo[i][1], x0, x1, x2); q[0][0] = (int)x0; q[1][0] = (int)x1; q[2][0] = (int)x2;
+            split3_pair(ralo[i][2], ralo[i][3], x0, x1, x2); q[0][1] = (int)x0; q[1][1] = (int)x1; q[2][1] = (int)x2;
+            split3_pair(rahi[i][0], rahi[i][1], x0, x1, x2); q[0][2] = (int)x0; q[1][2] = (int)x1; q[2][2] = (int)x2;
+            split3_pair(rahi[i][2], rahi[i][3], x0, x1, x2); q[0][3] = (int)x0; q[1][3] = (int)x1; q[2][3] = (int)x2;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(a + (pl * BM + srow + RP * i) * LDK + scol) = q[pl];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(b + (pl * BN + srow + RP * i) * LDK + scol) = rb[i][pl];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int nk = kt_end - kt_begin;
+    load_tiles(kt_begin * BK);
+    store_tiles();
+    __syncthreads();
+    if (nk > 1) load_tiles((kt_begin + 1) * BK);
+    // One LDS stage (61 KB for 128 x 128): TWO blocks fit a CU, and while one multiplies (matrix pipe) the other splits and
+    // stages its next tile (vector ALU + LDS writes) -- different units, so the two phases overlap across the blocks.
+    for (int k = 0; k < nk; ++k) {
+        const unsigned short* a = As + (wm * MI * 32 + frow) * LDK + fk;
+        const unsigned short* b = Bs + (wn * NI * 32 + frow) * LDK + fk;
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+            bf16x8 fa[MI][3], fb[NI][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a + (pl * BM + i * 32) * LDK + kb * 16);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + (pl * BN + j * 32) * LDK + kb * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    f32x16 c = acc[i][j];      // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                }
+        }
+        __syncthreads();                       // everybody has read this tile
+        if (k + 1 < nk) store_tiles();
+        __syncthreads();
+        if (k + 2 < nk) load_tiles((kt_begin + k + 2) * BK);
+    }
+    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+}
+
 // Sum the split-K partials and apply the fused epilogue (one float4 of channels per thread).
 __global__ void splitk_reduce_kernel(ConvParams p, int classes)
 {
@@ -892,6 +1066,29 @@ static hipError_t launch_f16(const ConvParams& p0, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WGM, int WGN>
+static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
+{
+    ConvParams p = p0;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (p.Cout_store + BN - 1) / BN;
+    constexpr size_t lds = (size_t)3 * (BM + BN) * 40 * sizeof(unsigned short);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
+    hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit <= 1) return e;
+    const long total = (long)grid.y * p.M * (p.Cout_store / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, (int)grid.y);
+    return hipGetLastError();
+}
+
 // Tile choice: the chip has 256 CUs; prefer the largest tile that still gives
 // >= ~2 blocks per CU, narrow-N tiles for the 2/19/72-channel layers.
 int conv_pick_tile(const ConvParams& p)
@@ -930,13 +1127,15 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if (tile >= 20 && tile <= 30) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS;
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
+           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5);
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
 {
     static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 256, 128, 128, 64, 128, 64};
     static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
+    if (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5) { static const int g[5] = {0, 1, 2, 3, 10}; tile = g[tile - CONV_TILE_B3]; }
     if (tile >= 31 && tile <= 35) { static const int g[5] = {3, 0, 2, 1, 4}; tile = g[tile - 31]; }   // deep-prefetch variants
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
     if (tile < 0 || tile > 19) tile = 3;
@@ -995,6 +1194,30 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
+    if (p.force_tile >= CONV_TILE_B3 && p.force_tile < CONV_TILE_B3 + 5 && !p.f16) {
+        // an fp32 layer on the bf16 matrix cores: same inputs and outputs, the products taken as 3 x bf16 splits
+        if (!p.wb3) return hipErrorInvalidValue;
+        ConvParams q = p;
+        q.w = static_cast<const float*>(p.wb3);
+        q.w_bytes = p.w_bytes / 2;               // one bf16 plane of one parity class
+        q.f16 = 2;
+        switch (p.force_tile - CONV_TILE_B3) {
+            case 0: return launch_b3<128, 128, 2, 2>(q, st);
+            case 1: return launch_b3<128, 64, 2, 2>(q, st);
+            case 2: return launch_b3<64, 128, 2, 2>(q, st);
+            case 3: return launch_b3<64, 64, 2, 2>(q, st);
+            default: return launch_b3<128, 128, 2, 4>(q, st);
+        }
+    }
+    if (p.f16 == 2) {      // fp32 split into three bf16 terms on the bf16 matrix cores: the same geometry ids
+        switch (conv_pick_tile(p)) {
+            case 0: case 5: return launch_b3<128, 128, 2, 2>(p, st);
+            case 1: case 6: return launch_b3<128, 64, 2, 2>(p, st);
+            case 2: case 7: return launch_b3<64, 128, 2, 2>(p, st);
+            case 10: return launch_b3<128, 128, 2, 4>(p, st);
+            default: return launch_b3<64, 64, 2, 2>(p, st);
+        }
+    }
     if (p.f16) {      // fp16-MFMA path: geometry ids 0-4 / 10-12 map onto the same tile shapes
         switch (conv_pick_tile(p)) {
             case 0: case 5: return launch_f16<128, 128, 2, 2>(p, st);

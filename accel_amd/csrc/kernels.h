@@ -33,7 +33,9 @@ struct ConvParams {
     int ksplit;            // >1: split-K over blockIdx.z, partials in ws, reduce+epilogue kernel follows
     int kt_per_split;
     int no_split;
-    int f16;               // weights packed as half, loader converts activations: fp16 MFMA, fp32 accumulate
+    int f16;               // 1: weights packed as half, loader converts activations: fp16 MFMA, fp32 accumulate;
+                           // 2: "bf16x3" -- fp32 operands split exactly into three bf16 terms, six bf16 MFMA products (fp32-equivalent)
+    size_t w_plane;        // f16 == 2: elements between the three bf16 planes of the packed weights
     int narrow;            // Cout <= 4 plain conv: wave-per-pixel dot-product kernel instead of the MFMA tile
     int split_target;      // >0: split K until the grid has about this many blocks (autotuner)
     float* ws;             // split-K workspace [ksplit][classes][M][Cout_store]
@@ -48,6 +50,8 @@ struct ConvParams {
     // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
     const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
     // weight-stationary streaming 1x1 variant (conv_1x1ws.hip, tile id 60): weights as the LDS image per column group
+    // bf16x3 variant of an fp32 layer (launch geometries 70-74): the weights once more, split into three bf16 planes
+    const void* wb3;       // null: Cin % 8 != 0, narrow output, or ACCEL_BF16X3=0
     const float* wws;      // null: not a 64 -> k*256 / 128 -> k*128 1x1 stride-1 layer (or ACCEL_WS1X1=0)
     unsigned wws_bytes;
 };
@@ -67,6 +71,7 @@ bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
+#define CONV_TILE_B3 70                  // 70..74: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10
 #define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)
 bool conv_ws_eligible(const ConvParams& p);
 size_t conv_ws_pack_floats(int Cin, int cout_store);

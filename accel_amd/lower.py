@@ -783,8 +783,10 @@ class Lowering(object):
             lines.append("option graph=0")
         if conv_dtype == "f16":
             lines.append("option dtype=f16")   # convolutions on the fp16 matrix cores (fp32 storage + accumulate)
+        elif conv_dtype == "bf16x3":
+            lines.append("option dtype=bf16x3")   # fp32 operands as three bf16 terms on the bf16 matrix cores (fp32-equivalent)
         elif conv_dtype != "f32":
-            raise ValueError("conv_dtype must be 'f32' or 'f16'")
+            raise ValueError("conv_dtype must be 'f32', 'f16' or 'bf16x3'")
         lines.append("meta feat_c=2048 feat_h=%d feat_w=%d feat_n=%d" % (self.H // 16, self.W // 16, self.N))
         lines.append("arena bytes=%d" % max(self.arena_bytes, ALIGN))
         for name, nbytes in sorted(self.pbufs.items()):

@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "8")),
                     help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
                          "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
-    ap.add_argument("--dtype", default=os.environ.get("ACCEL_CONV_DTYPE", "f32"), choices=["f32", "f16"],
-                    help="f32 (default, the reference's precision: the headline) or f16 = fp16-MFMA convolutions with fp32 "
-                         "storage/accumulate (BASELINE config 5; NOT the headline metric)")
+    ap.add_argument("--dtype", default=os.environ.get("ACCEL_CONV_DTYPE", "f32"), choices=["f32", "f16", "bf16x3"],
+                    help="f32 (default, the reference's precision on the fp32 MFMA: the headline); bf16x3 = the same fp32 values with every "
+                         "operand split exactly into three bf16 terms, six products on the bf16 matrix cores, fp32 accumulate "
+                         "(fp32-equivalent results, tests/test_bf16x3_gpu.py); f16 = fp16-MFMA convolutions with fp32 storage/"
+                         "accumulate (BASELINE config 5: reduced precision, never the headline)")
     ap.add_argument("--secondary", default="auto", choices=["auto", "none"],
                     help="auto: on a single GPU with the headline configuration also measure Accel-101, batch 1 and the "
                          "PCIe-inclusive loop (reported under `secondary`); none: headline only")
@@ -211,12 +213,14 @@ class Workload(object):
                     ms += wgt * float(d)
                     n += wgt
                     name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_f32_kernel" if op["tile"] == 40
-                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv1x1_ws_kernel" if op["tile"] == 60 else "conv_igemm_f16_kernel" if dtype != "f32" else "conv_igemm_f32_kernel")
+                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv1x1_ws_kernel" if op["tile"] == 60 else "conv_igemm_b3_kernel" if ((dtype == "bf16x3" and op["tile"] < 40) or 70 <= op["tile"] < 75) else "conv_igemm_f16_kernel" if dtype == "f16" else "conv_igemm_f32_kernel")
                     f = fam.setdefault(name, [0.0, 0.0, 0.0])
                     f[0] += wgt; f[1] += wgt * float(d); f[2] += wgt * op["flops"]
         clip_ms = float(kms.sum()) + (self.interval - 1) * float(cms.sum())
         ach = fl / (ms * 1e-3) / 1e12
-        peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+        # dense fp16 / bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md); bf16x3 executes SIX bf16 products per algorithmic
+        # multiply-add, so the roof of ALGORITHMIC flops is a sixth of it
+        peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else 2500.0 if dtype == "f16" else round(2500.0 / 6.0, 1)
         families = {k: {"launches_per_step": int(v[0]), "avg_launch_us": round(1e3 * v[1] / v[0], 2), "ms_per_step": round(v[1], 3),
                         "algorithmic_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0} for k, v in sorted(fam.items())}
         if "conv_wino_f32_kernel" in families:
@@ -333,7 +337,11 @@ def _run(a):
                "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80, batch 1, including H2D of the "
                                 "frame and D2H of the label map; vs_baseline = secondary.accel18_batch1_pcie_inclusive / that number "
                                 "(same timing definition, other hardware), null when that secondary was not measured",
-               "dtype": "f32" if a.dtype == "f32" else "f16 operands on the matrix cores, f32 storage + accumulate (reduced precision: not the headline)",
+               "dtype": "f32" if a.dtype == "f32" else
+                        "f32 as 3 x bf16 (each fp32 operand split exactly into three bf16 terms, six products per multiply-add on the bf16 "
+                        "matrix cores, f32 storage + accumulate; error vs float64 equal to the fp32-MFMA kernel's, tests/test_bf16x3_gpu.py)"
+                        if a.dtype == "bf16x3" else
+                        "f16 operands on the matrix cores, f32 storage + accumulate (reduced precision: not the headline)",
                "data": "synthetic",
                "config": {"workload": "Accel-%s (R101-DCN key branch + FlowNet-S warp + R%s correction branch + fused score tail), "
                                       "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step, "
