@@ -349,6 +349,30 @@ static int resolve(accel_plan* p, BufRef& r, const char* what)
 }
 
 // ---- weight repacking -------------------------------------------------------
+// fp32 packed weights [classes][rows][K_pad] (+ slack) -> the three bf16 planes of the bf16x3 kernel.  Each weight is split
+// exactly (top 16 bits, then of the residual, twice).  Inside a plane the order is [class][K step of 32][row][32]: the tile a
+// block fetches per K step (BN rows x 32 k) is then ONE contiguous run of BN x 64 bytes -- whole cache lines, where the
+// row-major order gave 64-byte pieces 2 * K_pad bytes apart.
+static void pack_bf16x3(const std::vector<float>& packed, int classes, int rows, int K_pad, std::vector<uint16_t>& out, size_t& plane)
+{
+    const int steps = K_pad / 32;
+    plane = (size_t)classes * rows * K_pad + 2 * (size_t)rows * 32;      // two K steps of slack: the kernel prefetches past the end
+    out.assign(3 * plane, 0);
+    for (int c = 0; c < classes; ++c)
+        for (int n = 0; n < rows; ++n)
+            for (int k = 0; k < K_pad; ++k) {
+                float r = packed[((size_t)c * rows + n) * K_pad + k];
+                const size_t dst = (((size_t)c * steps + k / 32) * rows + n) * 32 + (k & 31);
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t u; memcpy(&u, &r, 4);
+                    u &= 0xFFFF0000u;
+                    out[pl * plane + dst] = (uint16_t)(u >> 16);
+                    float t; memcpy(&t, &u, 4);
+                    r -= t;
+                }
+            }
+}
+
 // conv weights (Cout, Cin, kh, kw) -> [rows][K_pad], k = (ky*kw + kx)*cin_pad + ci
 static void pack_conv_w(const HostParam& w, int cin_pad, int rows, int K_pad, std::vector<float>& out)
 {
@@ -457,21 +481,9 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.f16 = (want_f16 && c.Cin % 8 == 0 && cout_store > 4) ? want_f16 : 0;
     void* dw_ = nullptr;
     if (c.f16 == 2) {
-        // exact three-way split of every weight into bf16 terms (top 16 bits, then of the residual, twice): planes [3][packed]
-        const size_t n = packed.size();
-        std::vector<uint16_t> pb(3 * n);
-        for (size_t i = 0; i < n; ++i) {
-            float r = packed[i];
-            for (int pl = 0; pl < 3; ++pl) {
-                uint32_t u; memcpy(&u, &r, 4);
-                u &= 0xFFFF0000u;
-                pb[pl * n + i] = (uint16_t)(u >> 16);
-                float t; memcpy(&t, &u, 4);
-                r -= t;
-            }
-        }
+        std::vector<uint16_t> pb;
+        pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
         if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &dw_))) return rc;
-        c.w_plane = n;
     } else if (c.f16) {
         std::vector<_Float16> ph(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
@@ -483,24 +495,13 @@ static int finalize_conv(accel_plan* p, Op& op)
         // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_BF16X3=0 withholds it)
         const char* be = getenv("ACCEL_BF16X3");
         const int ft = (int)kv_int(kv, "tile", -1);
-        const bool forced = ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 5;
+        const bool forced = ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 6;
         if (!c.f16 && c.Cin % 8 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
-            const size_t n = packed.size();
-            std::vector<uint16_t> pb(3 * n);
-            for (size_t i = 0; i < n; ++i) {
-                float r = packed[i];
-                for (int pl = 0; pl < 3; ++pl) {
-                    uint32_t u; memcpy(&u, &r, 4);
-                    u &= 0xFFFF0000u;
-                    pb[pl * n + i] = (uint16_t)(u >> 16);
-                    float t; memcpy(&t, &u, 4);
-                    r -= t;
-                }
-            }
+            std::vector<uint16_t> pb;
+            pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
             void* d3 = nullptr;
             if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
             c.wb3 = d3;
-            c.w_plane = n;
         } else if (forced) {
             return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with input channels in multiples of 8 and more than "
                                        "4 output channels only", op.name.c_str());
@@ -1024,7 +1025,7 @@ static int autotune_plan(accel_plan* p)
             if (c.wws) cs.push_back({CONV_TILE_WS, 0, 0});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
-                                        CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4};
+                                        CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && !nb3) continue;

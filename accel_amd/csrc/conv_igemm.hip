@@ -851,7 +851,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
         a_nb[i] = n * p.H * p.W;
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((size_t)(n0 + srow + RP * i) * p.K_pad + scol) * 2);
+    for (int i = 0; i < BR; ++i) b_off[i] = (unsigned)(((n0 + srow + RP * i) * 32 + scol) * 2);      // [K step][row][32] planes
+    const unsigned b_step = p.w_bytes / (unsigned)(p.K_pad / BK);      // bytes of one K step of one plane: rows x 64
 
     const int KT_all = p.K_pad / BK;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
 #pragma unroll
         for (int i = 0; i < BR; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], k0 * 2, 0);
+            for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], (k0 / BK) * b_step, 0);
     };
     auto store_tiles = [&]() {
         unsigned short* a = As;
@@ -1128,13 +1129,14 @@ bool conv_tile_valid(int tile)
     if (tile >= 20 && tile <= 30) return true;
 #endif
     return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
-           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5);
+           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 6);
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
 {
     static const int BMs[20] = {128, 128, 64, 64, 128, 128, 128, 64, 64, 128, 128, 128, 64, 64, 256, 128, 128, 64, 128, 64};
     static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
+    if (tile == CONV_TILE_B3 + 5) { bm = 256; bn = 128; return; }
     if (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5) { static const int g[5] = {0, 1, 2, 3, 10}; tile = g[tile - CONV_TILE_B3]; }
     if (tile >= 31 && tile <= 35) { static const int g[5] = {3, 0, 2, 1, 4}; tile = g[tile - 31]; }   // deep-prefetch variants
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
@@ -1194,7 +1196,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
-    if (p.force_tile >= CONV_TILE_B3 && p.force_tile < CONV_TILE_B3 + 5 && !p.f16) {
+    if (p.force_tile >= CONV_TILE_B3 && p.force_tile < CONV_TILE_B3 + 6 && !p.f16) {
         // an fp32 layer on the bf16 matrix cores: same inputs and outputs, the products taken as 3 x bf16 splits
         if (!p.wb3) return hipErrorInvalidValue;
         ConvParams q = p;
@@ -1206,6 +1208,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
             case 1: return launch_b3<128, 64, 2, 2>(q, st);
             case 2: return launch_b3<64, 128, 2, 2>(q, st);
             case 3: return launch_b3<64, 64, 2, 2>(q, st);
+            case 5: return launch_b3<256, 128, 4, 2>(q, st);     // 92 KB of LDS: one block per CU, 1.5x the flops per byte fetched
             default: return launch_b3<128, 128, 2, 4>(q, st);
         }
     }

@@ -71,7 +71,7 @@ bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
-#define CONV_TILE_B3 70                  // 70..74: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10
+#define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
 #define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)
 bool conv_ws_eligible(const ConvParams& p);
 size_t conv_ws_pack_floats(int Cin, int cout_store);
