@@ -903,6 +903,13 @@ struct TuneVal { int tile, split_target, no_split; };
 static std::map<TuneKey, TuneVal> g_tune_cache;
 static std::map<TuneKey, TuneVal> g_tune_shipped;      // entries of the in-tree table (never written back to the user file)
 static bool g_tune_loaded = false;
+// ACCEL_POISON=1 (debugging): fresh arenas, persistent buffers and workspaces are filled with NaN bit patterns, so a kernel
+// that consumes memory no op of the plan wrote shows up as NaNs in the outputs instead of as run-to-run noise
+static void poison(void* ptr, size_t bytes)
+{
+    static const char* e = getenv("ACCEL_POISON");
+    if (e && e[0] == '1' && ptr) { hipMemset(ptr, 0xFF, bytes); hipDeviceSynchronize(); }
+}
 static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a table / taken by timing in this process
 
 // Launch-geometry decisions are persisted so that they are REPRODUCIBLE: the summation order of a convolution (tile,
@@ -1045,6 +1052,7 @@ static int autotune_plan(accel_plan* p)
     if (ws_need > p->ws_bytes) {
         float* nw = nullptr;
         HIP_TRY(hipMalloc((void**)&nw, ws_need));
+        poison(nw, ws_need);
         p->owned.push_back(nw);
         p->ws = p->ws1 = nw; p->ws_bytes = ws_need;
         if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, ws_need)); p->owned.push_back(p->ws1); }
@@ -1098,6 +1106,9 @@ static int autotune_plan(accel_plan* p)
             it = g_tune_cache.insert({key, bv}).first;
             tuned_any = true;
             ++g_tune_timed;
+            if (getenv("ACCEL_TUNE_VERBOSE"))
+                fprintf(stderr, "[accel tune] %s: timed (not in a table): Cin %d Cout_store %d k %dx%d M %d -> geometry %d\n", op.name.c_str(),
+                        c.Cin, c.Cout_store, c.kh, c.kw, c.M, bv.tile);
         } else {
             ++g_tune_hits;
         }
@@ -1231,6 +1242,7 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     HIP_TRY(hipSetDevice(p->m->ctx->device));
     if (p->arena_bytes) {
         HIP_TRY(hipMalloc((void**)&p->arena, p->arena_bytes));
+        poison(p->arena, p->arena_bytes);
         HIP_TRY(hipMemsetAsync(p->arena, 0, p->arena_bytes, p->m->ctx->stream));
     }
     for (Op& op : p->ops) {
@@ -1250,6 +1262,7 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     }
     if (p->ws_bytes) {
         HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
+        poison(p->ws, p->ws_bytes);
         p->owned.push_back(p->ws);
         p->ws1 = p->ws;
         if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, p->ws_bytes)); p->owned.push_back(p->ws1); }

@@ -237,16 +237,19 @@ def test_headline_launch_geometries_are_replayed_not_timed(demo_cfg):
     demo_cfg.SCALES[0] = (H, W)
     arg, aux = synth.model_params("18", H, W, demo_cfg)
     data = demo.build_batches(synth.make_clip(H, W, 2), demo_cfg)
-    outs = []
+    outs, geo = [], []
     try:
         _, timed0, shipped = runtime.tune_stats()
         assert shipped > 0, "accel_amd/tune/gfx950.tune not found beside the library"
         for _ in range(2):
             r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
             outs.append([r.step(i, data[i], 2)[0].asnumpy().copy() for i in range(2)])
+            geo.append([(o["name"], o["tile"], o["ksplit"]) for pred in (r.key_predictor, r.cur_predictor)
+                        for o in pred.plan_for(H, W, 1)[0].ops() if o["kind"] == "conv"])
             r.close()
         replayed, timed1, _ = runtime.tune_stats()
         assert timed1 == timed0 and replayed > 0, "%d launch geometries were decided by timing" % (timed1 - timed0)
+        assert geo[0] == geo[1], [(a, b) for a, b in zip(*geo) if a != b][:6]
         for a, b in zip(*outs):
             np.testing.assert_array_equal(a, b)
     finally:
