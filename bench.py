@@ -223,6 +223,13 @@ class Workload(object):
         peak = MFMA_F32_PEAK_TFLOPS if dtype == "f32" else 2500.0 if dtype == "f16" else round(2500.0 / 6.0, 1)
         families = {k: {"launches_per_step": int(v[0]), "avg_launch_us": round(1e3 * v[1] / v[0], 2), "ms_per_step": round(v[1], 3),
                         "algorithmic_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0} for k, v in sorted(fam.items())}
+        if "conv_igemm_b3_kernel" in families:
+            f = families["conv_igemm_b3_kernel"]
+            f["executed_tflops"] = round(6.0 * f["algorithmic_tflops"], 1)
+            f["executed_peak_tflops"] = 2500.0
+            f["executed_frac"] = round(6.0 * f["algorithmic_tflops"] / 2500.0, 4)
+            f["note"] = ("fp32 values as three exact bf16 terms: SIX v_mfma_f32_32x32x16_bf16 products per algorithmic multiply-add; "
+                         "executed rate = 6 x algorithmic, against the dense bf16 peak (2500 TFLOP/s, MI355X_MICROARCH.md)")
         if "conv_wino_f32_kernel" in families:
             families["conv_wino_f32_kernel"]["note"] = ("Winograd F(2x2,3x3): executes 16/36 of the multiply-adds of the direct convolution "
                                                         "whose flops are counted here, so the algorithmic rate may exceed the matrix-core peak; "
@@ -230,6 +237,9 @@ class Workload(object):
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None, "traffic_note": None, "algorithmic_bytes_per_launch": round(by / n),
                 "kernel": "convolution kernels of the path (implicit GEMM + Winograd F(2x2,3x3) + 7x7 stem + weight-stationary 1x1 + narrow-N), per family below",
+                "frac_note": ("peak = the fp32-MFMA peak, the roof of a direct fp32 convolution; the algorithmic rate exceeds it where the launch "
+                              "geometry executes fewer (Winograd: 16/36) or faster (bf16x3: six bf16 products on the 16x faster bf16 pipe) "
+                              "operations per algorithmic multiply-add -- executed rates and their own peaks per family below"),
                 "achieved_note": "ALGORITHMIC flops (2 x MAC of the direct convolution after the two exact linear folds of DESIGN.md 4) of all conv "
                                  "launches of one step / the sum of their HIP-event durations",
                 "families": families, "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
@@ -337,7 +347,11 @@ def _run(a):
                "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80, batch 1, including H2D of the "
                                 "frame and D2H of the label map; vs_baseline = secondary.accel18_batch1_pcie_inclusive / that number "
                                 "(same timing definition, other hardware), null when that secondary was not measured",
-               "dtype": "f32" if a.dtype == "f32" else
+               "dtype": ("f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
+                         "and, for most implicit-GEMM layers, 'bf16x3': each fp32 operand split EXACTLY into three bf16 terms, six bf16 "
+                         "MFMA products accumulated in fp32 -- error against float64 equal to the fp32-MFMA kernel's, "
+                         "tests/test_bf16x3_gpu.py; secondary.*_fp32_mfma_only = without them)"
+                         if os.environ.get("ACCEL_BF16X3", "1") != "0" else "f32 (fp32 MFMA only: ACCEL_BF16X3=0)") if a.dtype == "f32" else
                         "f32 as 3 x bf16 (each fp32 operand split exactly into three bf16 terms, six products per multiply-add on the bf16 "
                         "matrix cores, f32 storage + accumulate; error vs float64 equal to the fp32-MFMA kernel's, tests/test_bf16x3_gpu.py)"
                         if a.dtype == "bf16x3" else
@@ -392,6 +406,23 @@ def _run(a):
                 w2.close()
             except Exception as e:
                 sec[name] = {"error": repr(e)}
+        if a.dtype == "f32" and os.environ.get("ACCEL_BF16X3", "1") != "0":
+            # the headline again with the fp32 MFMA for EVERY product (no bf16x3 launch geometries): the A/B of that choice
+            try:
+                os.environ["ACCEL_BF16X3"] = "0"
+                w3 = Workload(a.version, B, H, W, a.interval, local_rank, rank, config)
+                el = w3.timed(steps2, warm2)
+                rf = w3.conv_roofline(a.dtype)
+                sec["accel18_batch%d_fp32_mfma_only" % B] = {
+                    "value": rate(w3, el, steps2), "unit": "frames/s", "clips_per_call": B,
+                    "what": "the headline workload with ACCEL_BF16X3=0: every multiply-add on v_mfma_f32_* (Winograd where it wins), "
+                            "no 3 x bf16 split launch geometries",
+                    "conv_tflops": rf["achieved"], "conv_frac_of_peak": rf["frac"]}
+                w3.close()
+            except Exception as e:
+                sec["accel18_batch%d_fp32_mfma_only" % B] = {"error": repr(e)}
+            finally:
+                os.environ.pop("ACCEL_BF16X3", None)
         out["secondary"] = sec
     else:
         wl.close()
