@@ -836,7 +836,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     for (int pl = 0; pl < 3; ++pl) wr_[pl] = make_rsrc(wbase + pl * wplane, p.w_bytes);
     const int HoWo = p.Ho * p.Wo;
 
-    const int srow = tid / CPR, scol = (tid % CPR) * 8;
+    // Staging rows: a 16-byte LDS store is serviced 8 lanes at a time over 32 banks, and with 4 lanes per 64-byte row that is two
+    // rows per group.  Rows r and r+1 (80 bytes apart) share 4 banks -- a conflict on EVERY store, 29 % of all LDS cycles
+    // in the first version (SQ_LDS_BANK_CONFLICT) -- rows r and r+4 (320 bytes = 16 banks mod 32) share none: the rows of
+    // each group of 8 are taken in the order 0,4,1,5,2,6,3,7.
+    const int t4 = tid / CPR;
+    const int srow = (t4 & ~7) | ((t4 & 1) << 2) | ((t4 >> 1) & 3), scol = (tid % CPR) * 8;
     int a_iy0[AR], a_ix0[AR], a_nb[AR];
     unsigned b_off[BR];
 #pragma unroll

@@ -20,7 +20,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(float); n = collections.defaultdict(set)
 for f in glob.glob(sys.argv[1] + "/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "conv_igemm" not in r["Kernel_Name"] and "conv_wino" not in r["Kernel_Name"] and "conv_stem" not in r["Kernel_Name"]: continue
+        if not any(k in r["Kernel_Name"] for k in ("conv_igemm", "conv_wino", "conv_stem", "conv1x1_ws")): continue
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
 for k in sorted(acc): print("%-28s %16.0f per launch" % (k, acc[k] / max(len(n[k]), 1)))
 PY
