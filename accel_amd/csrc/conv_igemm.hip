@@ -801,7 +801,16 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& q0, un
     q2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// 16 bytes per lane, global -> LDS (lane i lands at lds + 16*i); outside the kernel template (see conv_1x1ws.hip)
+__device__ __forceinline__ void b3_dma16(__amdgpu_buffer_rsrc_t r, unsigned short* lds, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// WDMA: the weight planes travel global -> LDS by DMA (no registers, no ds_write), double-buffered and one K step ahead;
+// their rows are unpadded (64 bytes) with the 16-byte chunks XOR-swizzled by (row >> 2) & 3 on the SOURCE side, which
+// keeps the fragment reads conflict-free.
+template <int BM, int BN, int WGM, int WGN, bool WDMA>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParams p, size_t wplane)
 {
     constexpr int BK = 32, LDK = BK + 8;            // bf16 elements
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     static_assert(BM % RP == 0 && BN % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_b[];
     unsigned short* As = smem_b;                      // [3][BM][LDK]: ONE stage, two blocks per CU (see the loop)
-    unsigned short* Bs = smem_b + 3 * BM * LDK;       // [3][BN][LDK]
+    unsigned short* Bs = smem_b + 3 * BM * LDK;       // [3][BN][LDK]; WDMA: [2][3][BN][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -870,6 +879,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     unsigned a_base[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
+    // WDMA: instruction g of the block covers plane g / (BN/16), rows 16 * (g % (BN/16)) .. +16 (4 chunks each)
+    constexpr int NW = WGM * WGN, DPW = 3 * (BN / 16) / NW;      // DMA instructions per wavefront and K step
+    static_assert(!WDMA || (3 * (BN / 16)) % NW == 0, "weight DMA pieces do not divide over the wavefronts");
+    const unsigned dma_voff = (unsigned)(((n0 + (lane >> 2)) * 64) + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    const __amdgpu_buffer_rsrc_t wall = make_rsrc(wbase, (unsigned)(4 * wplane) + p.w_bytes);      // the three planes of this class
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_b = [&](int k0, int stage) {
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int g = wave_u * DPW + j, pl = g / (BN / 16), part = g % (BN / 16);
+            b3_dma16(wall, Bs + ((stage * 3 + pl) * BN + part * 16) * 32, dma_voff + (unsigned)(part * 1024),
+                     (unsigned)(pl * 2 * wplane) + (unsigned)((k0 / BK) * b_step));
+        }
+    };
     auto load_tiles = [&](int k0) {
         const int4 tk = tk_next;                 // the lane's own 8-wide chunk = two 4-wide granules of one tap
         tk_next = ktab[(k0 + BK + scol) / 4];
@@ -881,10 +904,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
             ralo[i] = buf_load4(xr, off);
             rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
         }
+        if (!WDMA) {
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
+            for (int i = 0; i < BR; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], (k0 / BK) * b_step, 0);
+                for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], (k0 / BK) * b_step, 0);
+        }
     };
     auto store_tiles = [&]() {
         unsigned short* a = As;
@@ -900,10 +925,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(a + (pl * BM + srow + RP * i) * LDK + scol) = q[pl];
         }
+        if (!WDMA) {
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
+            for (int i = 0; i < BR; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(b + (pl * BN + srow + RP * i) * LDK + scol) = rb[i][pl];
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(b + (pl * BN + srow + RP * i) * LDK + scol) = rb[i][pl];
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -916,15 +943,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     const int nk = kt_end - kt_begin;
+    if (WDMA) issue_b(kt_begin * BK, 0);
     load_tiles(kt_begin * BK);
+    if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_tiles();
     __syncthreads();
     if (nk > 1) load_tiles((kt_begin + 1) * BK);
-    // One LDS stage (61 KB for 128 x 128): TWO blocks fit a CU, and while one multiplies (matrix pipe) the other splits and
-    // stages its next tile (vector ALU + LDS writes) -- different units, so the two phases overlap across the blocks.
+    // One LDS stage for the pixel tile (two for the DMA'd weights): TWO blocks fit a CU, and while one multiplies (matrix
+    // pipe) the other splits and stages its next tile (vector ALU + LDS writes) -- different units, so the phases overlap.
     for (int k = 0; k < nk; ++k) {
+        if (WDMA && k + 1 < nk) issue_b((kt_begin + k + 1) * BK, (k + 1) & 1);      // lands while this tile is multiplied
         const unsigned short* a = As + (wm * MI * 32 + frow) * LDK + fk;
-        const unsigned short* b = Bs + (wn * NI * 32 + frow) * LDK + fk;
+        const unsigned short* b = WDMA ? Bs + ((k & 1) * 3 * BN + wn * NI * 32 + frow) * 32
+                                       : Bs + (wn * NI * 32 + frow) * LDK + fk;
 #pragma unroll
         for (int kb = 0; kb < BK / 16; ++kb) {
             bf16x8 fa[MI][3], fb[NI][3];
@@ -933,7 +964,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
 #pragma unroll
                 for (int i = 0; i < MI; ++i) fa[i][pl] = *reinterpret_cast<const bf16x8*>(a + (pl * BM + i * 32) * LDK + kb * 16);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) fb[j][pl] = *reinterpret_cast<const bf16x8*>(b + (pl * BN + j * 32) * LDK + kb * 16);
+                for (int j = 0; j < NI; ++j)
+                    fb[j][pl] = WDMA ? *reinterpret_cast<const bf16x8*>(b + (pl * BN + j * 32) * 32 + (((2 * kb + (lane >> 5)) ^ ((frow >> 2) & 3)) * 8))
+                                     : *reinterpret_cast<const bf16x8*>(b + (pl * BN + j * 32) * LDK + kb * 16);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -949,6 +982,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
                 }
         }
         __syncthreads();                       // everybody has read this tile
+        // the pixel registers of tile k+1 AND this wavefront's part of the weight DMA of tile k+1: nothing else is in flight
+        if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (k + 1 < nk) store_tiles();
         __syncthreads();
         if (k + 2 < nk) load_tiles((kt_begin + k + 2) * BK);
@@ -1078,16 +1113,17 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
-    constexpr size_t lds = (size_t)3 * (BM + BN) * 40 * sizeof(unsigned short);
+    constexpr bool WDMA = WGM * WGN == 8;      // measured: the DMA'd weight stream wins with 8 wavefronts (+5...14 %), loses with 4
+    constexpr size_t lds = WDMA ? (size_t)(3 * BM * 40 + 2 * 3 * BN * 32) * sizeof(unsigned short) : (size_t)3 * (BM + BN) * 40 * sizeof(unsigned short);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     const long total = (long)grid.y * p.M * (p.Cout_store / 4);
