@@ -810,7 +810,10 @@ __device__ __forceinline__ void b3_dma16(__amdgpu_buffer_rsrc_t r, unsigned shor
 // WDMA: the weight planes travel global -> LDS by DMA (no registers, no ds_write), double-buffered and one K step ahead;
 // their rows are unpadded (64 bytes) with the 16-byte chunks XOR-swizzled by (row >> 2) & 3 on the SOURCE side, which
 // keeps the fragment reads conflict-free.
-template <int BM, int BN, int WGM, int WGN, bool WDMA>
+// FAST (Cin % 32 == 0): a K step lies inside one tap, its table entry is wave-uniform and comes through the scalar unit.
+// Per lane (the general case) the entry of the NEXT step is a vector load whose result the compiler waits for on the
+// spot (a loop-carried copy): one exposed load latency per K step, 15-24 % of the kernel in the first version.
+template <int BM, int BN, int WGM, int WGN, bool WDMA, bool FAST>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParams p, size_t wplane)
 {
     constexpr int BK = 32, LDK = BK + 8;            // bf16 elements
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     f32x4 ralo[AR], rahi[AR];          // the activations travel as fp32 and are split when they are stored to LDS
     i32x4 rb[BR][3];
     const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
-    int4 tk_next = ktab[(kt_begin * BK + scol) / 4];
+    int4 tk_next = FAST ? ktab[(kt_begin * BK) / 4] : ktab[(kt_begin * BK + scol) / 4];
     unsigned a_base[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
@@ -885,6 +888,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     const unsigned dma_voff = (unsigned)(((n0 + (lane >> 2)) * 64) + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
     const __amdgpu_buffer_rsrc_t wall = make_rsrc(wbase, (unsigned)(4 * wplane) + p.w_bytes);      // the three planes of this class
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#ifdef B3_TIMING
+    long long tsub[2] = {0, 0};
+#endif
     auto issue_b = [&](int k0, int stage) {
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
@@ -894,21 +900,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
         }
     };
     auto load_tiles = [&](int k0) {
-        const int4 tk = tk_next;                 // the lane's own 8-wide chunk = two 4-wide granules of one tap
-        tk_next = ktab[(k0 + BK + scol) / 4];
+        int4 tk;
+        if (FAST) {
+            tk = tk_next;                        // uniform index: scalar loads, one K step ahead (re-issued at the END of this
+            tk.z += scol * 4;                    // function: scalar loads return out of order, so the compiler's wait for `tk`
+        } else {                                 // would otherwise also wait for the one just issued -- a full miss latency)
+            tk = tk_next;                        // the lane's own 8-wide chunk = two 4-wide granules of one tap
+            tk_next = ktab[(k0 + BK + scol) / 4];
+        }
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
+#ifdef B3_TIMING
+            asm volatile("s_nop 0" :: "v"(off));
+            const long long u0 = clock64();
+#endif
             ralo[i] = buf_load4(xr, off);
+#ifdef B3_TIMING
+            const long long u1 = clock64();
+#endif
             rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
+#ifdef B3_TIMING
+            const long long u2 = clock64(); tsub[0] += u1 - u0; tsub[1] += u2 - u1;
+#endif
         }
         if (!WDMA) {
 #pragma unroll
             for (int i = 0; i < BR; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wr_[pl], b_off[i], (k0 / BK) * b_step, 0);
+        }
+        if (FAST) {
+            __builtin_amdgcn_sched_barrier(0);
+            tk_next = ktab[(k0 + BK) / 4];
         }
     };
     auto store_tiles = [&]() {
@@ -951,7 +977,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     if (nk > 1) load_tiles((kt_begin + 1) * BK);
     // One LDS stage for the pixel tile (two for the DMA'd weights): TWO blocks fit a CU, and while one multiplies (matrix
     // pipe) the other splits and stages its next tile (vector ALU + LDS writes) -- different units, so the phases overlap.
+#ifdef B3_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    tsub[0] = tsub[1] = 0;
+#endif
     for (int k = 0; k < nk; ++k) {
+#ifdef B3_TIMING
+        const long long tq0 = clock64();
+#endif
         if (WDMA && k + 1 < nk) issue_b((kt_begin + k + 1) * BK, (k + 1) & 1);      // lands while this tile is multiplied
         const unsigned short* a = As + (wm * MI * 32 + frow) * LDK + fk;
         const unsigned short* b = WDMA ? Bs + ((k & 1) * 3 * BN + wn * NI * 32 + frow) * 32
@@ -981,13 +1014,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
                 }
         }
+#ifdef B3_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[MI - 1][NI - 1][15]));
+        const long long tq1 = clock64(); tacc[0] += tq1 - tq0;
+#endif
         __syncthreads();                       // everybody has read this tile
+#ifdef B3_TIMING
+        const long long tq2 = clock64(); tacc[1] += tq2 - tq1;
+#endif
         // the pixel registers of tile k+1 AND this wavefront's part of the weight DMA of tile k+1: nothing else is in flight
         if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef B3_TIMING
+        const long long tq3 = clock64(); tacc[2] += tq3 - tq2;
+#endif
         if (k + 1 < nk) store_tiles();
+#ifdef B3_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long tq4 = clock64(); tacc[3] += tq4 - tq3;
+#endif
         __syncthreads();
+#ifdef B3_TIMING
+        const long long tq5 = clock64(); tacc[4] += tq5 - tq4;
+#endif
         if (k + 2 < nk) load_tiles((kt_begin + k + 2) * BK);
+#ifdef B3_TIMING
+        tacc[5] += clock64() - tq5;
+#endif
     }
+#ifdef B3_TIMING
+    if (blockIdx.x == 777 && lane == 0) { for (int i = 0; i < 6; ++i) p.y[wave * 8 + i] = (float)tacc[i] / (float)nk; p.y[wave * 8 + 6] = (float)tsub[0] / (float)nk; p.y[wave * 8 + 7] = (float)tsub[1] / (float)nk; }
+    if (blockIdx.x == 777) return;
+#endif
     conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 }
 
@@ -1117,13 +1174,17 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
     constexpr size_t lds = WDMA ? (size_t)(3 * BM * 40 + 2 * 3 * BN * 32) * sizeof(unsigned short) : (size_t)3 * (BM + BN) * 40 * sizeof(unsigned short);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    else hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     const long total = (long)grid.y * p.M * (p.Cout_store / 4);
