@@ -47,7 +47,7 @@ def test_conv_bf16x3_every_geometry_within_the_fp32_tolerance(ctx, b3_mode, tile
     assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))     # the fp32 operator bar of test_ops_gpu
 
 
-@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74])
+@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74, 75])
 def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
     """In fp32 mode the kernel is offered to the autotuner as launch geometries 70-74 of the same convolution."""
     from accel_amd.runtime import AccelError
