@@ -149,7 +149,10 @@ class Predictor(object):
         # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
         # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
         pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
-        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
+        # ONE stream by default.  Two (the per-frame branch beside FlowNet / warp / head, ACCEL_MULTI_STREAM=1) gain 0.6 % at 8 clips
+        # per call and, with the bf16x3 launch geometries, produced intermittent localized errors in 1 of 10-30 runs of the
+        # folded-vs-layer-by-layer clip comparison (never in 62 single-stream runs): off until the cause is known.
+        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "0") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
                   fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
         text, lw = _lower.lower(self._symbol, shapes, feat_slot=0 if pingpong else None, **kw)
         pingpong = pingpong and any(getattr(getattr(v, "buf", None), "space", None) == "feat_b" for v in lw.outputs.values())

@@ -879,7 +879,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     i32x4 rb[BR][3];
     const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
     int4 tk_next = FAST ? ktab[(kt_begin * BK) / 4] : ktab[(kt_begin * BK + scol) / 4];
-    int4 tk2_next = ktab[(kt_begin * BK + scol) / 4 + 1];      // general case only
     unsigned a_base[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
@@ -901,32 +900,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
         }
     };
     auto load_tiles = [&](int k0) {
-        if constexpr (FAST) {
-            int4 tk = tk_next;                   // uniform index: scalar loads, one K step ahead (re-issued at the END of this
+        int4 tk;
+        if (FAST) {
+            tk = tk_next;                        // uniform index: scalar loads, one K step ahead (re-issued at the END of this
             tk.z += scol * 4;                    // function: scalar loads return out of order, so the compiler's wait for `tk`
-#pragma unroll                                   // would otherwise also wait for the one just issued -- a full miss latency)
-            for (int i = 0; i < AR; ++i) {
-                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
-                ralo[i] = buf_load4(xr, off);
-                rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
-            }
-        } else {
-            // the lane's own 8-wide chunk = two 4-wide granules, each with its own tap entry (with Cin % 8 == 4 the second
-            // granule may belong to the next tap: FlowNet's deconvolutions read 386 / 770 / 1026 channels)
-            const int4 tk = tk_next, tk2 = tk2_next;
+        } else {                                 // would otherwise also wait for the one just issued -- a full miss latency)
+            tk = tk_next;                        // the lane's own 8-wide chunk = two 4-wide granules of one tap
             tk_next = ktab[(k0 + BK + scol) / 4];
-            tk2_next = ktab[(k0 + BK + scol) / 4 + 1];
+        }
 #pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const int iy2 = a_iy0[i] + tk2.x, ix2 = a_ix0[i] + tk2.y;
-                const bool ok2 = (unsigned)iy2 < (unsigned)p.H && (unsigned)ix2 < (unsigned)p.W;
-                ralo[i] = buf_load4(xr, ok ? a_base[i] + (unsigned)tk.z : OOB);
-                rahi[i] = buf_load4(xr, ok2 ? a_base[i] + (unsigned)tk2.z : OOB);
-            }
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
+#ifdef B3_TIMING
+            asm volatile("s_nop 0" :: "v"(off));
+            const long long u0 = clock64();
+#endif
+            ralo[i] = buf_load4(xr, off);
+#ifdef B3_TIMING
+            const long long u1 = clock64();
+#endif
+            rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
+#ifdef B3_TIMING
+            const long long u2 = clock64(); tsub[0] += u1 - u0; tsub[1] += u2 - u1;
+#endif
         }
         if (!WDMA) {
 #pragma unroll
@@ -1185,7 +1183,8 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
         attr_done = true;
     }
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    static const char* nofast = getenv("ACCEL_B3_NOFAST");      // debugging: the general (per-lane table) load path for every layer
+    if (p.Cin % 32 == 0 && !(nofast && nofast[0] == '1')) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     else hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaccel_hip.so")
+LIB_PATH = os.environ.get("ACCEL_LIB_PATH") or os.path.join(_HERE, "libaccel_hip.so")      # (override: A/B of two builds)
 _lib = None
 
 
