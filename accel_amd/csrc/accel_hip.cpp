@@ -478,7 +478,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     const char* env_dt = getenv("ACCEL_CONV_DTYPE");   // "f16": also for the single-operator entry points
     const int dflt = (p->f16 == 2 || (env_dt && !strcmp(env_dt, "bf16x3"))) ? 2 : (p->f16 || (env_dt && !strcmp(env_dt, "f16"))) ? 1 : 0;
     const int want_f16 = (int)kv_int(kv, "f16", dflt);
-    c.f16 = (want_f16 && c.Cin % 8 == 0 && cout_store > 4) ? want_f16 : 0;
+    c.f16 = (want_f16 && c.Cin % (want_f16 == 2 ? 4 : 8) == 0 && cout_store > 4) ? want_f16 : 0;
     void* dw_ = nullptr;
     if (c.f16 == 2) {
         std::vector<uint16_t> pb;
@@ -496,14 +496,14 @@ static int finalize_conv(accel_plan* p, Op& op)
         const char* be = getenv("ACCEL_BF16X3");
         const int ft = (int)kv_int(kv, "tile", -1);
         const bool forced = ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 6;
-        if (!c.f16 && c.Cin % 8 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
+        if (!c.f16 && c.Cin % 4 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
             std::vector<uint16_t> pb;
             pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
             void* d3 = nullptr;
             if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
             c.wb3 = d3;
         } else if (forced) {
-            return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with input channels in multiples of 8 and more than "
+            return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with more than "
                                        "4 output channels only", op.name.c_str());
         }
     }

@@ -879,6 +879,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
     i32x4 rb[BR][3];
     const int4* ktab = p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0);
     int4 tk_next = FAST ? ktab[(kt_begin * BK) / 4] : ktab[(kt_begin * BK + scol) / 4];
+    int4 tk2_next = ktab[(kt_begin * BK + scol) / 4 + 1];      // general case only
     unsigned a_base[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) a_base[i] = (unsigned)(((a_nb[i] + a_iy0[i] * p.W + a_ix0[i]) * p.xCs) * 4);
@@ -900,31 +901,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_b3_kernel(ConvParam
         }
     };
     auto load_tiles = [&](int k0) {
-        int4 tk;
-        if (FAST) {
-            tk = tk_next;                        // uniform index: scalar loads, one K step ahead (re-issued at the END of this
+        if constexpr (FAST) {
+            int4 tk = tk_next;                   // uniform index: scalar loads, one K step ahead (re-issued at the END of this
             tk.z += scol * 4;                    // function: scalar loads return out of order, so the compiler's wait for `tk`
-        } else {                                 // would otherwise also wait for the one just issued -- a full miss latency)
-            tk = tk_next;                        // the lane's own 8-wide chunk = two 4-wide granules of one tap
+#pragma unroll                                   // would otherwise also wait for the one just issued -- a full miss latency)
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
+                ralo[i] = buf_load4(xr, off);
+                rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
+            }
+        } else {
+            // the lane's own 8-wide chunk = two 4-wide granules, each with its own tap entry (with Cin % 8 == 4 the second
+            // granule may belong to the next tap: FlowNet's deconvolutions read 386 / 770 / 1026 channels)
+            const int4 tk = tk_next, tk2 = tk2_next;
             tk_next = ktab[(k0 + BK + scol) / 4];
-        }
+            tk2_next = ktab[(k0 + BK + scol) / 4 + 1];
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const unsigned off = ok ? a_base[i] + (unsigned)tk.z : OOB;
-#ifdef B3_TIMING
-            asm volatile("s_nop 0" :: "v"(off));
-            const long long u0 = clock64();
-#endif
-            ralo[i] = buf_load4(xr, off);
-#ifdef B3_TIMING
-            const long long u1 = clock64();
-#endif
-            rahi[i] = buf_load4(xr, ok ? off + 16u : OOB);
-#ifdef B3_TIMING
-            const long long u2 = clock64(); tsub[0] += u1 - u0; tsub[1] += u2 - u1;
-#endif
+            for (int i = 0; i < AR; ++i) {
+                const int iy = a_iy0[i] + tk.x, ix = a_ix0[i] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int iy2 = a_iy0[i] + tk2.x, ix2 = a_ix0[i] + tk2.y;
+                const bool ok2 = (unsigned)iy2 < (unsigned)p.H && (unsigned)ix2 < (unsigned)p.W;
+                ralo[i] = buf_load4(xr, ok ? a_base[i] + (unsigned)tk.z : OOB);
+                rahi[i] = buf_load4(xr, ok2 ? a_base[i] + (unsigned)tk2.z : OOB);
+            }
         }
         if (!WDMA) {
 #pragma unroll

@@ -55,8 +55,13 @@ def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
     ref = O.relu(O.conv2d(x, w, b, 2, 2, 2) + res)
     got = ctx.conv2d(x, w, b, 2, 2, 2, residual=res, act=1, tile=tile)
     assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    # channel counts that are not multiples of 8: the two 4-wide granules of a lane's chunk may lie in different taps
+    for C in (36, 3, 20):
+        xc, wc = rnd(28, 1, C, 17, 19), rnd(29, 40, C, 3, 3, scale=(2.0 / (9 * C)) ** 0.5)
+        refc = O.conv2d(xc, wc, None, 1, 1, 1)
+        assert float(np.abs(ctx.conv2d(xc, wc, None, 1, 1, 1, tile=tile) - refc).max()) <= 1e-4 * max(1.0, float(np.abs(refc).max())), C
     with pytest.raises(AccelError, match="bf16x3"):
-        ctx.conv2d(rnd(26, 1, 3, 16, 16), rnd(27, 64, 3, 3, 3), None, 1, 1, 1, tile=tile)      # 3 input channels
+        ctx.conv2d(rnd(26, 1, 16, 16, 16), rnd(27, 2, 16, 3, 3), None, 1, 1, 1, tile=tile)      # 2 output channels: the strip kernel's layer
 
 
 @pytest.mark.parametrize("C,K,H,W,k,s,p,d", CASES)
@@ -82,6 +87,9 @@ def test_conv_bf16x3_error_is_of_the_order_of_the_fp32_kernels(ctx, C, K, H, W, 
 
 
 def test_deconv_and_dcn_bf16x3(ctx, b3_mode):
+    xo, wo = rnd(14, 2, 386, 8, 12), rnd(15, 386, 64, 4, 4, scale=0.03)      # FlowNet deconv2: 386 = 256 + 128 + 2 channels
+    refo = O.deconv2d(xo, wo, None, 2, 1)
+    assert float(np.abs(ctx.deconv2d_4x4s2(xo, wo) - refo).max()) <= 1e-4 * max(1.0, float(np.abs(refo).max()))
     x, w = rnd(4, 1, 64, 9, 13), rnd(5, 64, 32, 4, 4, scale=0.1)
     ref = O.deconv2d(x, w, None, 2, 1)
     assert float(np.abs(ctx.deconv2d_4x4s2(x, w) - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
