@@ -149,11 +149,14 @@ class Predictor(object):
         # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
         # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
         pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
-        # ONE stream by default.  Two (the per-frame branch beside FlowNet / warp / head, ACCEL_MULTI_STREAM=1) gain 0.6 % at 8 clips
-        # per call and, with the bf16x3 launch geometries, produced intermittent localized errors in 1 of 10-30 runs of the
-        # folded-vs-layer-by-layer clip comparison (never in 62 single-stream runs): off until the cause is known.
-        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "0") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
-                  fold_linear=os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0")
+        # Two streams (the per-frame branch beside FlowNet / warp / head) for the default lowering; ONE stream when the linear
+        # folds are off (ACCEL_FOLD_LINEAR=0: the reference's layer list one to one).  That plan, with the bf16x3 geometries and
+        # two streams, came out wrong in about half of its bindings (errors of 0.5 over whole frames, scratch/bind2s.py; never
+        # on one stream, never with ACCEL_BF16X3=0, and the folded plan never in 50 bindings): cause not found yet, DESIGN.md 7.
+        # ACCEL_MULTI_STREAM=0 / 1 overrides either way.
+        fold = os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
+        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1" if fold else "0") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
+                  fold_linear=fold)
         text, lw = _lower.lower(self._symbol, shapes, feat_slot=0 if pingpong else None, **kw)
         pingpong = pingpong and any(getattr(getattr(v, "buf", None), "space", None) == "feat_b" for v in lw.outputs.values())
         if not pingpong and lw.feat_slot is not None:
