@@ -41,8 +41,12 @@ def params_token(*dicts):
     repacked weights in HBM -- only when their parameters are the same BYTES; another network or another checkpoint
     gets its own model instead of overwriting same-named weights (fc6_weight, score_weight ... exist in every Accel
     variant).  ~0.1 s for the 0.45 GB of Accel-18."""
-    import xxhash
-    h = xxhash.xxh3_64()
+    try:
+        import xxhash
+        h = xxhash.xxh3_64()
+    except ImportError:          # optional dependency: the standard library's blake2b is ~5x slower and just as good
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
     for d in dicts:
         for k in sorted(d):
             v = d[k]
@@ -136,7 +140,9 @@ class Predictor(object):
         shapes.update(self._extra_shapes)
         self._check_params(self._symbol, shapes)
         model = self._explicit_model
-        token = params_token(self._arg_params, self._aux_params)
+        if getattr(self, "_token", None) is None:      # one hash per predictor, not per bound shape
+            self._token = params_token(self._arg_params, self._aux_params)
+        token = self._token
         if model is None:
             model = shared_model(self._device_id, (N, H, W), token, self._owner)
         if getattr(model, "_params_token", None) != token:
@@ -149,14 +155,21 @@ class Predictor(object):
         # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
         # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
         pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
-        # Two streams (the per-frame branch beside FlowNet / warp / head) for the default lowering; ONE stream when the linear
-        # folds are off (ACCEL_FOLD_LINEAR=0: the reference's layer list one to one).  That plan, with the bf16x3 geometries and
-        # two streams, came out wrong in about half of its bindings (errors of 0.5 over whole frames, scratch/bind2s.py; never
-        # on one stream, never with ACCEL_BF16X3=0, and the folded plan never in 50 bindings): cause not found yet, DESIGN.md 7.
-        # ACCEL_MULTI_STREAM=0 / 1 overrides either way.
+        # ONE stream by default.  A two-stream lowering exists (the per-frame correction branch on a side stream beside
+        # FlowNet / warp / head: +2-5 % at one clip per call, nothing at 8 clips per call), but on this ROCm / gfx950 stack
+        # kernels of the side stream occasionally read 256-byte granules of data that an EARLIER kernel of the same stream
+        # produced as if they had not been written, while a bandwidth-heavy kernel of the other hardware queue is running
+        # (DESIGN.md 7 "two-stream hazard", scripts/debug/twostream_bisect.py: not a missing dependency of the plan, not a
+        # hipGraph effect, not a kernel of this library -- kernel order, arena layout, explicit L2 fences were all ruled
+        # out).  ACCEL_MULTI_STREAM=1 opts in and warns once.
         fold = os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
-        kw = dict(multi_stream=os.environ.get("ACCEL_MULTI_STREAM", "1" if fold else "0") != "0", conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"),
-                  fold_linear=fold)
+        multi = os.environ.get("ACCEL_MULTI_STREAM", "0") == "1"
+        if multi and not getattr(Predictor, "_warned_multi", False):
+            import warnings
+            warnings.warn("ACCEL_MULTI_STREAM=1: two-stream plans can return wrong frames on this stack (DESIGN.md 7, "
+                          "two-stream hazard); results are not covered by the parity tests", RuntimeWarning)
+            Predictor._warned_multi = True
+        kw = dict(multi_stream=multi, conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"), fold_linear=fold)
         text, lw = _lower.lower(self._symbol, shapes, feat_slot=0 if pingpong else None, **kw)
         pingpong = pingpong and any(getattr(getattr(v, "buf", None), "space", None) == "feat_b" for v in lw.outputs.values())
         if not pingpong and lw.feat_slot is not None:

@@ -1058,15 +1058,27 @@ static int autotune_plan(accel_plan* p)
         if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, ws_need)); p->owned.push_back(p->ws1); }
         for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    struct TuneScratch {      // released on every way out of this function
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        void* scrub = nullptr;
+        hipStream_t st;
+        ~TuneScratch()
+        {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            if (scrub) { hipStreamSynchronize(st); hipFree(scrub); }
+        }
+    } ts;
+    ts.st = st;
+    HIP_TRY(hipEventCreate(&ts.e0)); HIP_TRY(hipEventCreate(&ts.e1));
+    hipEvent_t e0 = ts.e0, e1 = ts.e1;
     int rc = 0;
     const size_t scrub_bytes = (size_t)320 << 20;      // > L2 (8 x 4 MB) + Infinity Cache (256 MB)
-    void* scrub = nullptr;
     {
         const char* e = getenv("ACCEL_TUNE_COLD");
-        if (!(e && e[0] == '0') && hipMalloc(&scrub, scrub_bytes) != hipSuccess) scrub = nullptr;
+        if (!(e && e[0] == '0') && hipMalloc(&ts.scrub, scrub_bytes) != hipSuccess) ts.scrub = nullptr;
     }
+    void* const scrub = ts.scrub;
     for (size_t i = 0; i < p->ops.size() && !rc; ++i) {
         if (cands[i].empty()) continue;
         Op& op = p->ops[i];
@@ -1114,8 +1126,6 @@ static int autotune_plan(accel_plan* p)
         }
         conv_apply(c, it->second.tile, it->second.split_target, it->second.no_split);
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    if (scrub) { hipStreamSynchronize(st); hipFree(scrub); }
     if (tuned_any && !rc) tune_cache_save();
     return rc;
 }
@@ -1275,44 +1285,56 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     // writes are live model state (a non-key plan warps `feat` / `featG` in place; a lazily bound plan is finalized
     // between two frames of a clip), so they are saved first and put back afterwards: finalizing a plan never changes
     // what the next forward sees.  Derived-buffer validity is untouched for the same reason.
-    struct Saved { std::string name; void* copy; size_t bytes; };
-    std::vector<Saved> saved;
-    auto restore = [&]() -> int {
-        hipStream_t st = p->m->ctx->stream;
-        int rc = 0;
-        for (Saved& sv : saved) {
-            if (!rc && hipMemcpyAsync(p->m->pbufs[sv.name].ptr, sv.copy, sv.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
-                rc = fail(ACCEL_ERR_HIP, "restoring persistent buffer %s after plan finalisation failed", sv.name.c_str());
+    // (RAII: whatever way this function is left -- including every HIP_TRY early return below -- the snapshot is copied
+    // back and freed.)
+    struct Snapshot {
+        accel_plan* p;
+        struct Saved { std::string name; void* copy; size_t bytes; };
+        std::vector<Saved> saved;
+        int restore()
+        {
+            hipStream_t st = p->m->ctx->stream;
+            int rc = 0;
+            for (Saved& sv : saved)
+                if (!rc && hipMemcpyAsync(p->m->pbufs[sv.name].ptr, sv.copy, sv.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    rc = fail(ACCEL_ERR_HIP, "restoring persistent buffer %s after plan finalisation failed", sv.name.c_str());
+            if (!saved.empty() && hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(ACCEL_ERR_HIP, "sync after plan finalisation failed");
+            for (Saved& sv : saved) hipFree(sv.copy);
+            saved.clear();
+            return rc;
         }
-        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(ACCEL_ERR_HIP, "sync after plan finalisation failed");
-        for (Saved& sv : saved) hipFree(sv.copy);
-        saved.clear();
-        return rc;
-    };
+        ~Snapshot()
+        {
+            if (saved.empty()) return;
+            const std::string keep = g_err;      // an error path: the message of the original failure stays
+            restore();
+            g_err = keep;
+        }
+    } snap{p, {}};
     if (p->allow_tune || use_graph) {
         for (const std::string& name : p->pbuf_writes) {
             DevBuf& b = p->m->pbufs[name];
-            Saved sv{name, nullptr, b.bytes};
-            if (hipMalloc(&sv.copy, b.bytes) != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "hipMalloc(%zu) for the snapshot of %s failed", b.bytes, name.c_str()); }
-            saved.push_back(sv);
-            if (hipMemcpyAsync(sv.copy, b.ptr, b.bytes, hipMemcpyDeviceToDevice, p->m->ctx->stream) != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "snapshot of %s failed", name.c_str()); }
+            Snapshot::Saved sv{name, nullptr, b.bytes};
+            if (hipMalloc(&sv.copy, b.bytes) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipMalloc(%zu) for the snapshot of %s failed", b.bytes, name.c_str());
+            snap.saved.push_back(sv);
+            if (hipMemcpyAsync(sv.copy, b.ptr, b.bytes, hipMemcpyDeviceToDevice, p->m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "snapshot of %s failed", name.c_str());
         }
     }
-    if (p->allow_tune) { int trc = autotune_plan(p); if (trc) { restore(); return trc; } HIP_TRY(hipDeviceSynchronize()); }
+    if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
     if (use_graph) {
         hipStream_t st = p->m->ctx->stream;
         // one eager warm-up run: lazy module loading / function attributes must not happen under capture
         int rc = run_eager(p);
-        if (rc) { restore(); return rc; }
+        if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         rc = run_eager(p);
         hipError_t e = hipStreamEndCapture(st, &p->graph);
-        if (rc) { restore(); return rc; }
-        if (e != hipSuccess) { restore(); return fail(ACCEL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
         HIP_TRY(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
     }
-    int rrc = restore();
+    int rrc = snap.restore();
     if (rrc) return rrc;
     p->finalized = true;
     return 0;
@@ -1393,6 +1415,29 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
     for (auto& e : ev) hipEventDestroy(e);
     for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
     return rc;
+}
+
+// ---- diagnostics: the plan's ops one after the other on ONE stream (no graph, no side stream), and the arena ---------------
+extern "C" int accel_plan_run_serial(accel_plan* p)
+{
+    if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run_serial: plan not finalized");
+    for (Op& op : p->ops) {
+        int rc = launch_op(p, op, true);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    return 0;
+}
+
+extern "C" int accel_plan_arena_read(accel_plan* p, size_t offset, void* host_dst, size_t bytes, size_t* arena_bytes)
+{
+    if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_arena_read: plan not finalized");
+    if (arena_bytes) *arena_bytes = p->arena_bytes;
+    if (!host_dst || !bytes) return 0;
+    if (offset + bytes > p->arena_bytes) return fail(ACCEL_ERR_ARG, "accel_plan_arena_read: %zu + %zu bytes > arena (%zu)", offset, bytes, p->arena_bytes);
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    HIP_TRY(hipMemcpy(host_dst, p->arena + offset, bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device)

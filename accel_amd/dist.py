@@ -51,15 +51,44 @@ def as_torch(ptr, shape, dtype="f4", device=0):
 
 def make_comm(ctx, group=None):
     """RCCL communicator of the C ABI (accel_comm_create) spanning the ranks of a torch.distributed group: the 128-byte
-    unique id is made on rank 0 and handed to the others through the process group (the rendezvous torch.distributed
-    already did); everything after that is libaccel_hip + librccl, no torch on the data path."""
+    unique id is made on the group's first rank and handed to the others through the process group (the rendezvous
+    torch.distributed already did); everything after that is libaccel_hip + librccl, no torch on the data path.
+
+    The decision is COLLECTIVE: every rank takes part in the same broadcast and the same success vote, and either all
+    ranks get a communicator or all get None (and the reason) -- a rank that cannot resolve librccl, or whose
+    ncclCommInitRank fails, never leaves the others blocked in a broadcast or in a different transport."""
+    import torch
     import torch.distributed as dist
     from . import runtime
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [runtime.Comm.unique_id() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if (group is not None and hasattr(dist, "get_global_rank")) else 0
+    box = [None]
+    if rank == 0:
+        try:
+            box = [runtime.Comm.unique_id()]
+        except Exception as e:
+            box = [RuntimeError("rank 0: %s" % (e,))]
     if world > 1:
-        dist.broadcast_object_list(box, src=0, group=group)
-    return runtime.Comm(ctx, rank, world, box[0])
+        dist.broadcast_object_list(box, src=src, group=group)
+    comm, why = None, ""
+    if isinstance(box[0], Exception) or box[0] is None:
+        why = str(box[0])
+    else:
+        try:
+            comm = runtime.Comm(ctx, rank, world, box[0])
+        except Exception as e:
+            why = "rank %d: %s" % (rank, e)
+    if world > 1:
+        backend = dist.get_backend(group)
+        dev = "cuda:%d" % ctx.device_id if backend == "nccl" else "cpu"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm, why = None, "another rank could not create its communicator"
+    if comm is None:
+        raise runtime.AccelError("C-ABI communicator unavailable on every rank: %s" % (why or "unknown reason"))
+    return comm
 
 
 class FrameGather(object):

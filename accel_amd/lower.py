@@ -35,6 +35,17 @@ def _r4(c):
     return (c + 3) // 4 * 4
 
 
+def _forced_tiles():
+    """diagnostics: ACCEL_FORCE_TILE="18_conv0=3,fc6=74" pins the launch geometry of the named convolutions"""
+    import os
+    out = {}
+    for tok in os.environ.get("ACCEL_FORCE_TILE", "").split(","):
+        if "=" in tok:
+            k, v = tok.split("=", 1)
+            out[k.strip()] = int(v)
+    return out
+
+
 class VBuf(object):
     """A physical buffer: arena slot (offset assigned later) or persistent."""
 
@@ -82,7 +93,7 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, multi_stream=True, fold_linear=True, feat_slot=None):
+    def __init__(self, sym, input_shapes, ncls=19, multi_stream=False, fold_linear=True, feat_slot=None):
         self.sym = sym
         self.fold_linear = bool(fold_linear)
         # Ping-pong of the propagated feature (non-key graphs): a warp cannot run in place, so the plan either warps into
@@ -130,7 +141,8 @@ class Lowering(object):
         only_data = [n for n in compute if self.deps[id(n)] == frozenset(["data"])]
         self.two_streams = bool(multi_stream) and 0 < len(only_data) < len(compute)
         self.cur_stream = 0
-        self.last_writer = {}   # buffer key -> (op index, stream)
+        self.last_writer = {}   # buffer key -> {stream: index of the last op that wrote it}
+        self.last_reader = {}   # buffer key -> {stream: index of the last op that read it}
         data_shape = input_shapes["data"]
         self.N, self.H, self.W = int(data_shape[0]), int(data_shape[2]), int(data_shape[3])
         self.nsfx = "" if self.N == 1 else ":%d" % self.N     # batch suffix of literal buffer references
@@ -211,21 +223,41 @@ class Lowering(object):
         for v in list(reads) + list(writes):
             if v is not None:
                 v.buf.streams.add(st)
+        # Cross-stream ordering (two-stream plans).  Per buffer and stream the plan remembers the LAST op that wrote and the
+        # last op that read it; in-order execution inside a stream covers the older ones.  A read waits for the last writer on
+        # every other stream (several producers may fill channel slices of one concat buffer from different streams); a
+        # write waits for the other streams' last readers and writers of that buffer as well (write-after-read / -write).
         waits = set()
         for v in reads:
             if v is None:
                 continue
-            w = self.last_writer.get(self._bkey(v))
-            if w is not None and w[1] != st:
-                waits.add(w[0])
+            for s_, w in self.last_writer.get(self._bkey(v), {}).items():
+                if s_ != st:
+                    waits.add(w)
+        for v in writes:
+            if v is None:
+                continue
+            k = self._bkey(v)
+            for s_, w in self.last_writer.get(k, {}).items():
+                if s_ != st:
+                    waits.add(w)
+            for s_, r in self.last_reader.get(k, {}).items():
+                if s_ != st:
+                    waits.add(r)
+        for v in reads:
+            if v is not None:
+                self.last_reader.setdefault(self._bkey(v), {})[st] = idx
         for v in writes:
             if v is not None:
-                self.last_writer[self._bkey(v)] = (idx, st)
+                self.last_writer.setdefault(self._bkey(v), {})[st] = idx
         if self.two_streams:
             args["stream"] = st
             if waits:
                 args["wait"] = ",".join(str(w) for w in sorted(waits))
         n = self.N if n is None else n
+        force = _forced_tiles().get(args.get("name"))
+        if force is not None and kind == "conv":
+            args["tile"] = force       # diagnostics: ACCEL_FORCE_TILE="opname=tile,..."
         flops, nbytes = flops * n, nbytes * n + nbytes_fixed     # callers give per-image work (+ weights, read once)
         if flops:
             args["flops"] = "%.6g" % flops
@@ -752,6 +784,15 @@ class Lowering(object):
         therefore packed per stream into disjoint arena regions; buffers touched by both streams
         (join inputs) get private space."""
         live = [b for b in self.bufs if b.first is not None]
+        import os
+        if os.environ.get("ACCEL_ARENA_NO_REUSE") == "1":
+            # diagnostics: every buffer keeps private space, so the arena after a run holds every op's own output
+            total = 0
+            for b in live:
+                b.off = total
+                total += (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
+            self.arena_bytes = total
+            return
 
         def pack(bufs, base):
             placed, total = [], 0
@@ -842,6 +883,6 @@ def init_plan_text(name, d):
                                            d["from"], cin, _r4(cin), H, W, sfx, 2.0 * N * H * W * cin * cout)]) + "\n"
 
 
-def lower(sym, input_shapes, graph=True, multi_stream=True, conv_dtype="f32", fold_linear=True, feat_slot=None):
+def lower(sym, input_shapes, graph=True, multi_stream=False, conv_dtype="f32", fold_linear=True, feat_slot=None):
     lw = Lowering(sym, input_shapes, multi_stream=multi_stream, fold_linear=fold_linear, feat_slot=feat_slot).run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

@@ -58,6 +58,8 @@ def _declare(lib):
         "accel_plan_num_ops": [vp],
         "accel_plan_op_info": [vp, i, c.c_char_p, c.c_char_p, c.POINTER(c.c_double), c.POINTER(c.c_double)],
         "accel_plan_profile": [vp, i, vp, i],
+        "accel_plan_run_serial": [vp],
+        "accel_plan_arena_read": [vp, sz, vp, sz, c.POINTER(sz)],
         "accel_model_write": [vp, c.c_char_p, vp, sz, i],
         "accel_model_read": [vp, c.c_char_p, vp, sz, i],
         "accel_model_buffer": [vp, c.c_char_p, c.POINTER(vp), c.POINTER(sz)],
@@ -328,6 +330,18 @@ class Plan(object):
             check(lib().accel_plan_op_launch(self.handle, i, ctypes.byref(t), ctypes.byref(k), ctypes.byref(nw)))
             out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value,
                         "tile": t.value, "ksplit": k.value, "narrow": nw.value})
+        return out
+
+    def run_serial(self):
+        """diagnostics: every op in list order on the context stream (no graph, no side stream), then a host wait"""
+        check(lib().accel_plan_run_serial(self.handle))
+
+    def arena(self):
+        """diagnostics: host copy of the plan's activation arena (uint8)"""
+        n = ctypes.c_size_t()
+        check(lib().accel_plan_arena_read(self.handle, 0, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        check(lib().accel_plan_arena_read(self.handle, 0, _fp(out), out.nbytes, None))
         return out
 
     def profile(self, iters=3):

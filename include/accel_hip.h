@@ -93,6 +93,14 @@ int accel_tune_stats(int* replayed, int* timed, int* shipped_entries);
  * the context stream; ms[i] = mean duration of op i */
 int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);
 
+/* Diagnostics (scripts/debug, tests): the ops of a finalized plan launched one after the other on the context stream --
+ * no captured graph, no side stream -- followed by a host wait; and a host copy of a byte range of the plan's activation
+ * arena (arena_bytes, if given, receives its size; host_dst may be NULL to query only).  Comparing the arena after a
+ * normal accel_plan_run with the arena after accel_plan_run_serial of the same bound plan names the first op whose
+ * output depends on the schedule. */
+int accel_plan_run_serial(accel_plan* p);
+int accel_plan_arena_read(accel_plan* p, size_t offset, void* host_dst, size_t bytes, size_t* arena_bytes);
+
 /* persistent buffers (inputs `data`/`data_key`, outputs `logits`/`labels`, the
  * propagated feature `feat`): DataParallelExecutorGroup._load_general copy-in
  * (:18-27) and get_outputs (:357-378) */

@@ -197,6 +197,62 @@ def test_plan_is_well_formed(demo_cfg, version, key):
     assert "Concat" not in text and all(k in ("prep_rgb", "prep_flow", "conv", "pool", "warp", "dcn_cols", "score_tail", "copy") for k in kinds)
 
 
+def test_default_lowering_is_single_stream(demo_cfg):
+    """One stream unless asked: the two-stream lowering is opt-in (two-stream hazard)."""
+    for version in ("18", "34", "50", "101"):
+        text, lw = _plan(version, False)
+        assert not lw.two_streams and "stream=" not in text
+        text2, lw2 = _plan(version, False, multi_stream=True)
+        assert lw2.two_streams and " stream=1" in text2
+
+
+@pytest.mark.parametrize("version", ["18", "34", "50", "101"])
+@pytest.mark.parametrize("fold", [True, False])
+def test_two_stream_plans_order_every_conflict(demo_cfg, version, fold):
+    """Opt-in two-stream plans: every pair of ops on DIFFERENT streams that touch the same buffer with at least one write
+    (read-after-write, write-after-read, write-after-write; persistent buffers by name, arena buffers by byte range) is
+    ordered by the plan's `wait=` edges together with in-stream order."""
+    text, lw = _plan(version, False, multi_stream=True, fold_linear=fold, feat_slot=0)
+    ops = []
+    for line in (l for l in text.splitlines() if l and not l.startswith(("#", "arena", "pbuf", "option", "meta"))):
+        kv = dict(t.split("=", 1) for t in line.split()[1:])
+        acc = []
+        for k, v in kv.items():
+            m = re.match(r"^(\w+):(\d+):(\d+):(\d+):(\d+):(\d+)(?::(\d+))?$", v)
+            if not m:
+                continue
+            space, off, C, Cs, H, W = m.group(1), *map(int, m.groups()[1:6])
+            n = int(m.group(7) or 1)
+            rng = (space, off, off + ((n * H * W - 1) * Cs + C) * 4) if space == "A" else (space, 0, 1)
+            acc.append((rng, k in ("out", "out2", "dst", "logits", "labels")))
+        ops.append((int(kv.get("stream", 0)), [int(w) for w in kv.get("wait", "").split(",") if w], acc))
+    n = len(ops)
+    # happens-before: same stream and earlier, or reachable through a wait edge
+    before = [set() for _ in range(n)]
+    last_on = {}
+    for i, (st, waits, _) in enumerate(ops):
+        preds = list(waits)
+        if st in last_on:
+            preds.append(last_on[st])
+        for j in preds:
+            before[i].add(j)
+            before[i] |= before[j]
+        last_on[st] = i
+    # the side stream forks at the start of the plan and joins at its end: only these edges order the two streams
+    checked = 0
+    for i in range(n):
+        for j in range(i):
+            if ops[i][0] == ops[j][0]:
+                continue
+            for (ra, wa) in ops[i][2]:
+                for (rb, wb) in ops[j][2]:
+                    if not (wa or wb) or ra[0] != rb[0] or ra[2] <= rb[1] or rb[2] <= ra[1]:
+                        continue
+                    checked += 1
+                    assert j in before[i], "ops %d and %d touch %s on different streams without an ordering edge" % (j, i, ra[0])
+    assert checked > 0
+
+
 @pytest.mark.parametrize("version", ["18", "50"])
 def test_feature_pingpong_variants(demo_cfg, version):
     """Non-key graphs bind as two plans that hand the propagated feature back and forth between `feat`/`featG` and
