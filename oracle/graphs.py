@@ -16,6 +16,22 @@ EPS_DCN = 1e-5      # self.eps, resnet_v1_101_flownet_deeplab.py:23
 EPS_PREACT = 2e-5   # residual_unit / resnet(), :50-75,108
 
 
+# DeformableConvolution is discontinuous where a sampling position crosses the image border (ops.deform_border_taps).
+# While RECORD is a list, every deformable layer appends (layer name, input stride in image pixels, (k, 3) array of the
+# output pixels (n, oy, ox) that have a tap within BORDER_EPS of that discontinuity): the parity checks may tolerate a
+# deviation ONLY around such a pixel (tests/parity_report.py).
+RECORD = None
+BORDER_EPS = 1e-4
+
+
+def _dcn(name, stride_px, x, off, w, stride, pad, dilate, dg):
+    if RECORD is not None:
+        pts = O.deform_border_taps(x.shape[2], x.shape[3], off, w.shape[2:], stride, pad, dilate, BORDER_EPS)
+        if len(pts):
+            RECORD.append((name, stride_px, pts))
+    return O.deform_conv2d(x, off, w, stride=stride, pad=pad, dilate=dilate, dg=dg)
+
+
 def _bn(P, name, x, eps, fix_gamma=False):
     return O.batchnorm(x, P[name + "_gamma"], P[name + "_beta"],
                        P[name + "_moving_mean"], P[name + "_moving_var"], eps, fix_gamma)
@@ -57,8 +73,7 @@ def resnet_dcn_bottleneck(P, data, units, prefix, unit_namer, dcn_dg, offset_dil
                     off = _conv(P, oname, y, pad=2, dilate=2, bias=True)
                 else:                # 18-ch, pad 1 (:1232-1234)
                     off = _conv(P, oname, y, pad=1, bias=True)
-                y = O.deform_conv2d(y, off, P[p + "res" + u + "_branch2b_weight"],
-                                    stride=1, pad=2, dilate=2, dg=dcn_dg)
+                y = _dcn(p + "res" + u + "_branch2b", 16, y, off, P[p + "res" + u + "_branch2b_weight"], 1, 2, 2, dcn_dg)
             else:
                 y = _conv(P, p + "res" + u + "_branch2b", y, pad=1)
             y = O.relu(_bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN))
@@ -124,7 +139,7 @@ def resnet_dcn_conv5_basic(P, feat, prefix, n_units):
             y = _conv(P, p + "res" + u + "_branch2a", x, stride=1, pad=1)
         y = O.relu(_bn(P, p + "bn" + u + "_branch2a", y, EPS_DCN))
         off = _conv(P, p + "res" + u + "_branch2b_offset", y, pad=2, dilate=2, bias=True)
-        y = O.deform_conv2d(y, off, P[p + "res" + u + "_branch2b_weight"], 1, 2, 2, dg=4)
+        y = _dcn(p + "res" + u + "_branch2b", 32, y, off, P[p + "res" + u + "_branch2b_weight"], 1, 2, 2, 4)
         y = _bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN)
         x = O.relu(sc + y)
     return x
@@ -270,21 +285,43 @@ def run_clip(P, version, frames, interval):
     idx % interval == 0 -> key graph, else cur graph with data_key = PREVIOUS
     frame and feat_key = previously propagated feature (demo.py:176-181,241).
     Returns per-frame (logits, labels)."""
+    global RECORD
     version = str(version)
-    outs = []
+    outs = ClipResult()
     feat = None
     prev = None
+    carried = []       # discontinuity points of the key frame: they travel with the propagated feature
     for idx, im in enumerate(frames):
         if prev is None:
             prev = im
+        saved, RECORD = RECORD, []
+        try:
+            if idx % interval == 0:
+                o = key_forward(P, im)
+                feat = o["res5c_relu_output"]
+                logits = o["croped_score_output"]
+            else:
+                o = cur_forward(P, version, im, prev, feat)
+                feat = o["warping_feat_output"]
+                logits = o["croped_score_output" if version in ("101", "dff") else "correction_output"]
+            pts = [(name, int(n), (oy + 0.5) * s, (ox + 0.5) * s) for name, s, arr in RECORD for n, oy, ox in arr]
+        finally:
+            RECORD = saved
         if idx % interval == 0:
-            o = key_forward(P, im)
-            feat = o["res5c_relu_output"]
-            logits = o["croped_score_output"]
+            carried = list(pts)
+            outs.critical.append(list(pts))
         else:
-            o = cur_forward(P, version, im, prev, feat)
-            feat = o["warping_feat_output"]
-            logits = o["croped_score_output" if version in ("101", "dff") else "correction_output"]
+            outs.critical.append(carried + pts)
         prev = im
         outs.append((logits, O.argmax_c(logits)))
     return outs
+
+
+class ClipResult(list):
+    """run_clip's result: a list of per-frame (logits, labels) that also carries, per frame, the image positions
+    (layer, image index, y, x) of the deformable-convolution pixels that have a tap within BORDER_EPS of the border
+    discontinuity -- in this frame's own layers and, on non-key frames, in the key frame whose feature they propagate."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.critical = []

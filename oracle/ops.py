@@ -124,6 +124,33 @@ def deform_conv2d(x, offset, w, stride=1, pad=0, dilate=1, dg=1):
     return y
 
 
+def deform_border_taps(H, W, offset, kernel, stride, pad, dilate, eps):
+    """Output pixels (n, oy, ox) of a DeformableConvolution with at least one sampling position within `eps` of the
+    DISCONTINUITY of the DCN-v1 rule (orc_deform_im2col above): a tap contributes 0 for h_im < 0 or h_im >= H and the
+    border row's value just inside, likewise in w -- so a last-bit difference in an offset that sits within eps of 0 or
+    of H (W) legitimately switches that tap on or off.  Returns an int array (k, 3).  float64 throughout."""
+    off = np.asarray(offset, np.float64)
+    N, ch, Ho, Wo = off.shape
+    kh, kw = _pair(kernel)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(pad)
+    dh, dw = _pair(dilate)
+    dg = ch // (2 * kh * kw)
+    off = off.reshape(N, dg, kh * kw, 2, Ho, Wo)
+    i = (np.arange(kh * kw) // kw).reshape(1, 1, -1, 1, 1)
+    j = (np.arange(kh * kw) % kw).reshape(1, 1, -1, 1, 1)
+    oy = np.arange(Ho).reshape(1, 1, 1, -1, 1)
+    ox = np.arange(Wo).reshape(1, 1, 1, 1, -1)
+    h_im = oy * sh - ph + i * dh + off[:, :, :, 0]
+    w_im = ox * sw - pw + j * dw + off[:, :, :, 1]
+    near_h = (np.abs(h_im) < eps) | (np.abs(h_im - H) < eps)
+    near_w = (np.abs(w_im) < eps) | (np.abs(w_im - W) < eps)
+    live_h = (h_im > -eps) & (h_im < H + eps)
+    live_w = (w_im > -eps) & (w_im < W + eps)
+    crit = ((near_h & live_w) | (near_w & live_h)).any(axis=(1, 2))
+    return np.argwhere(crit)
+
+
 def bn_fold(gamma, beta, mean, var, eps, fix_gamma=False):
     gamma, gp = _f(gamma)
     beta, bp = _f(beta)

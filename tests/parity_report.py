@@ -1,7 +1,9 @@
 """Shared parity check of whole-clip runs against the CPU oracle, with the label-margin histogram SURVEY.md 7
 ("hard parts") asks for.
 
-Logits: |hip - oracle| <= 1e-3 * max(1, max|oracle|)   (BASELINE.json north star: "logits within 1e-3 fp32").
+Logits: |hip - oracle| <= max(1e-3, 1e-5 * max|oracle|)   (BASELINE.json north star: "logits within 1e-3 fp32"; logits
+of +-110 have an fp32 ulp of 7.6e-6, hence the second term) -- everywhere, except inside at most two 64x64 windows per
+frame that are each VERIFIED to sit at a deformable-convolution border discontinuity the oracle itself recorded.
 Labels: with e = the MEASURED max logit error of the frame, a label can legitimately differ from the oracle's only
 where the oracle's top-2 margin is <= 2e (top-1 down by e, runner-up up by e).  So labels must be IDENTICAL wherever
 margin > 2e -- that is "bit-exact argmax" up to the measured rounding band, not up to the allowed tolerance -- and the
@@ -31,24 +33,36 @@ def margin_histogram(ref_logits, labels, ref_labels, err, tol):
     return margin, rows
 
 
-def flip_windows(err_map, tol, win=64, max_windows=2):
-    """Covers the pixels of `err_map` (H x W) that exceed `tol` with at most `max_windows` windows of win x win pixels.
-    Returns (mask of covered pixels, list of window centres) or raises AssertionError if they do not fit.
+RADIUS = 128      # image pixels: how far from a discontinuity point a tolerated deviation may peak (three more dilated 3x3
+                  # layers of res5 at stride 16 or the 4x4/2 deconvolution at stride 32, the 32x32/16 upsampling kernel,
+                  # and the few pixels the warp moves the propagated feature per frame)
 
-    Why windows are tolerated at all: DeformableConvolution (DCN v1) is DISCONTINUOUS where a sampling position crosses
+
+def flip_windows(err_map, tol, win=64, max_windows=2, critical=None, radius=RADIUS):
+    """Covers the pixels of `err_map` (H x W) that exceed `tol` with at most `max_windows` windows of win x win pixels,
+    EACH of which must be explained: its peak has to lie within `radius` pixels of a point of `critical` -- the image
+    positions (y, x) at which the ORACLE saw a deformable-convolution tap within 1e-4 px of the border discontinuity
+    (oracle.graphs.ClipResult.critical / ops.deform_border_taps).  With critical=None nothing is tolerated.
+    Returns (mask of covered pixels, list of window centres) or raises AssertionError.
+
+    Why such windows exist at all: DeformableConvolution (DCN v1) is DISCONTINUOUS where a sampling position crosses
     the image border (zero for h < 0, the border pixel's value at h = 0; same at the far side), so a last-bit difference
-    in an offset can switch one tap of one stride-16 feature pixel on or off.  That moves the logits inside the 32x32
-    footprint of that feature pixel (one 16x bilinear upsampling kernel, wider after a warp) by whole units -- on ANY two
-    implementations that do not round identically (measured on the direct path alone: a 1e-5 relative perturbation of
-    the input moves one feature pixel of a 1024x2048 key frame by 6.7, DESIGN.md "numerics").  Everything outside such a
-    footprint must meet the tolerance; more than `max_windows` footprints per frame fail the test."""
+    in an offset can switch one tap of one stride-16 feature pixel on or off.  That moves the logits inside the footprint
+    of that feature pixel by whole units -- on ANY two implementations that do not round identically (measured on the
+    direct path alone: a 1e-5 relative perturbation of the input moves one feature pixel of a 1024x2048 key frame by
+    6.7, DESIGN.md "numerics").  Everything else must meet the tolerance."""
     e = np.array(err_map, dtype=np.float32, copy=True)
     mask = np.zeros(e.shape, bool)
     centres = []
+    pts = np.asarray([(p[-2], p[-1]) for p in (critical or [])], np.float64).reshape(-1, 2)
     while float(e.max()) > tol:
-        assert len(centres) < max_windows, "errors above %g do not fit into %d isolated %dx%d windows (first at %s)" % (
-            tol, max_windows, win, win, centres)
         y, x = np.unravel_index(int(np.argmax(e)), e.shape)
+        assert len(centres) < max_windows, "errors above %g do not fit into %d isolated %dx%d windows (%s, next at %s)" % (
+            tol, max_windows, win, win, centres, (int(y), int(x)))
+        d = np.sqrt(((pts - (y, x)) ** 2).sum(axis=1)).min() if len(pts) else np.inf
+        assert d <= radius, ("error %.3g at pixel (%d, %d) is not explained by a deformable-convolution border tap: the "
+                             "nearest of the oracle's %d discontinuity points is %.0f px away (allowed %d)"
+                             % (float(e[y, x]), y, x, len(pts), d, radius))
         y0, x0 = max(0, y - win // 2), max(0, x - win // 2)
         e[y0:y0 + win, x0:x0 + win] = 0.0
         mask[y0:y0 + win, x0:x0 + win] = True
@@ -56,24 +70,35 @@ def flip_windows(err_map, tol, win=64, max_windows=2):
     return mask, centres
 
 
-def check_against_oracle(outs, ref, tag, rel_tol=1e-3, max_mismatch=1e-3):
+def logit_tolerance(ref_logits, abs_tol=1e-3, rel_tol=1e-5):
+    """BASELINE.json north star: "logits within 1e-3 fp32" -- absolute; on logits beyond +-100 (the synthetic weights reach
+    +-110) one fp32 ulp of the value is 7.6e-6, so the bound is 1e-3 or 1e-5 of the largest logit, whichever is larger."""
+    return max(abs_tol, rel_tol * float(np.abs(ref_logits).max()))
+
+
+def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=1e-5, max_mismatch=1e-3, max_windows=2):
     lines = []
+    crit_all = getattr(ref, "critical", None)
     for t, ((lg, lab), (rlg, rlab)) in enumerate(zip(outs, ref)):
-        tol = rel_tol * max(1.0, float(np.abs(rlg).max()))
+        tol = logit_tolerance(rlg, abs_tol, rel_tol)
         emap = np.abs(lg - rlg).max(axis=(0, 1))
-        flips, centres = flip_windows(emap, tol)
-        if centres:      # isolated DCN border flips (see flip_windows): excluded from the checks below, reported here
-            lines.append("%s frame %d: %d isolated discontinuity footprint(s) around %s (max err there %.3g) -- excluded"
-                         % (tag, t, len(centres), centres, float(emap.max())))
+        crit = None
+        if crit_all is not None:
+            crit = crit_all[t]
+        flips, centres = flip_windows(emap, tol, max_windows=max_windows, critical=crit)
+        if centres:      # verified DCN border flips (see flip_windows): excluded from the checks below, reported here
+            lines.append("%s frame %d: %d discontinuity footprint(s) around %s (max err there %.3g), each within %d px of one "
+                         "of the oracle's %d border-tap points -- excluded"
+                         % (tag, t, len(centres), centres, float(emap.max()), RADIUS, len(crit or [])))
             keep = ~flips
             lg, rlg = np.where(keep, lg, rlg), rlg
             lab = np.where(keep, np.asarray(lab).reshape(rlab.shape), rlab)
         err = float(np.abs(lg - rlg).max())
         lab = np.asarray(lab).reshape(rlab.shape)
         margin, rows = margin_histogram(rlg, lab, rlab, err, tol)
-        lines.append("%s frame %d: max|logit err| e=%.3g (tol %.3g, |logit|max %.3g); pixels / label mismatches per oracle "
-                     "top-2 margin bin: %s" % (tag, t, err, tol, float(np.abs(rlg).max()),
-                                               "  ".join("%s %d/%d" % (n, c, m) for n, c, m in rows)))
+        lines.append("%s frame %d: max|logit err| e=%.3g (tol %.3g, |logit|max %.3g, %d border-tap points); pixels / label "
+                     "mismatches per oracle top-2 margin bin: %s" % (tag, t, err, tol, float(np.abs(rlg).max()), len(crit or []),
+                                                                    "  ".join("%s %d/%d" % (n, c, m) for n, c, m in rows)))
         assert err <= tol, "%s frame %d: logits err %g > %g" % (tag, t, err, tol)
         safe = margin > 2 * err
         np.testing.assert_array_equal(lab[safe], rlab[safe], err_msg="%s frame %d: label differs outside the measured rounding band" % (tag, t))
@@ -87,3 +112,32 @@ def check_against_oracle(outs, ref, tag, rel_tol=1e-3, max_mismatch=1e-3):
     except OSError:
         pass
     return lines
+
+
+def hip_border_points(plan, lw, eps=1e-4):
+    """The same discontinuity points as oracle.graphs.ClipResult.critical, but from the HIP run's OWN offsets: for
+    comparisons of two HIP evaluations where no oracle run exists.  Needs a plan bound with ACCEL_ARENA_NO_REUSE=1
+    (every intermediate buffer keeps private space, so the offset maps are still in the arena after the run).
+    Returns [(layer, image index, y, x)] in image pixels."""
+    from oracle import ops as O
+    from accel_amd.lower import View
+    arena = None
+    pts = []
+    for kind, args in lw.ops:
+        if kind != "dcn_cols":
+            continue
+        offv, xin = args["off"], args["in"]
+        assert isinstance(offv, View) and offv.buf.space == "A"
+        if arena is None:
+            arena = plan.arena()
+        b = offv.buf
+        a = arena[b.off:b.off + b.nbytes].view(np.float32).reshape(b.N, b.H, b.W, b.Cs)[..., offv.coff:offv.coff + offv.C]
+        off = np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+        kk = tuple(int(v) for v in args["k"].split(","))
+        st = tuple(int(v) for v in args["s"].split(","))
+        pd = tuple(int(v) for v in args["p"].split(","))
+        dl = tuple(int(v) for v in args["d"].split(","))
+        stride_px = lw.H // xin.buf.H
+        for n, oy, ox in O.deform_border_taps(xin.buf.H, xin.buf.W, off, kk, st, pd, dl, eps):
+            pts.append((args["name"], int(n), (oy + 0.5) * stride_px, (ox + 0.5) * stride_px))
+    return pts

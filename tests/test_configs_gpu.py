@@ -2,10 +2,11 @@
 
   config 1  Accel-18, 512x1024 two-frame pair, key-frame interval 1 (both frames key, the reference's own
             CPU-runnable case) and interval 2 (the warp / correction path) -- against the CPU oracle;
+  config 2  Accel-18 1024x2048 against the CPU oracle at full size (key + two non-key frames, both lowerings);
   config 2/4  Accel-18 1024x2048, 8 clips per call (what bench.py times): the batched call against eight
             batch-1 runs of the same clips;
-  config 3  Accel-101 1024x2048: the size-independent properties of test_golden_gpu.py for the other model
-            the BASELINE metric names;
+  config 3  Accel-101 1024x2048 against the CPU oracle at full size, and the size-independent properties of
+            test_golden_gpu.py for the other model the BASELINE metric names;
   config 4  the RCCL gather of per-frame logits, on one GPU (world size 1): gathered bytes == logits buffer;
   config 5  Accel-50 with fp16-MFMA convolutions at 2048x4096, key-frame interval 10 schedule (3 frames of it):
             finite logits, labels agree with the fp32 run of the same clip.
@@ -19,7 +20,7 @@ import pytest
 from accel_amd.utils import image, synth
 from oracle import graphs as G
 
-from parity_report import check_against_oracle, flip_windows
+from parity_report import check_against_oracle, flip_windows, hip_border_points, logit_tolerance
 
 pytestmark = pytest.mark.gpu
 
@@ -49,13 +50,16 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
     check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
 
 
-def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg):
+def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkeypatch):
     """What bench.py times: one call = one frame of each of 8 independent clips at 1024x2048.  Image b of the batched
     call must reproduce the batch-1 run of clip b over a key and a non-key frame (tile choices differ between the two
     binds, so sums may differ in the last bits: 1e-4 of the logit range; labels identical outside the tie band)."""
     from accel_amd import demo, mx
     from accel_amd.core import tester
     H, W, B, interval = 1024, 2048, 8, 2
+    # private space for every intermediate buffer: the offset maps of the deformable layers survive the run, and a
+    # deviation between the two evaluations is tolerated only at a border discontinuity those offsets show
+    monkeypatch.setenv("ACCEL_ARENA_NO_REUSE", "1")
     demo_cfg.SCALES[0] = (H, W)
     arg, aux = synth.model_params("18", H, W, demo_cfg)
     clips = [synth.make_clip(H, W, interval, seed=4100 + b) for b in range(B)]
@@ -70,23 +74,72 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg):
                 single[b][t] = (lg.asnumpy()[0][:, ::2, ::2].copy(), np.uint8(lab.asnumpy()[0]))
         tester.release_models()
         rb = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W), batch=B)
+        carried = []
         for t in range(interval):
             arrays = [mx.nd.array(np.concatenate([per_clip[b][t][i].asnumpy() for b in range(B)], axis=0)) for i in range(2)]
             arrays.append(mx.nd.array(np.zeros((B, 2048, 1, 1), np.float32)))
             logits, labels = rb.step(t, arrays, interval)
             lg, lab = logits.asnumpy(), labels.asnumpy()
             assert lg.shape == (B, 19, H, W) and lab.shape == (B, H, W)
+            pred = rb.key_predictor if t % interval == 0 else rb.cur_predictor
+            pts = hip_border_points(*pred.plan_for(H, W, B, slot=0))
+            carried = pts if t % interval == 0 else carried + pts
             for b in range(B):
                 ref, rlab = single[b][t]
-                tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+                tol = logit_tolerance(ref)
                 emap = np.abs(lg[b][:, ::2, ::2] - ref).max(axis=0)
-                # outside isolated DCN border-flip footprints (parity_report.flip_windows) the two runs agree to 1e-4
-                flips, centres = flip_windows(emap, tol, win=32)
+                # the two evaluations (other launch geometries, other summation order) agree to the logit tolerance, except
+                # inside footprints of a border discontinuity that this run's own offsets show (parity_report.flip_windows)
+                crit = [(name, n, y / 2, x / 2) for name, n, y, x in carried if n == b]
+                flips, centres = flip_windows(emap, tol, win=32, critical=crit, radius=64)
                 if centres:
-                    print("batch-8 vs single, frame %d clip %d: discontinuity footprint(s) at %s" % (t, b, centres))
+                    print("batch-8 vs single, frame %d clip %d: verified discontinuity footprint(s) at %s" % (t, b, centres))
                 assert float((np.uint8(lab[b]) != rlab).mean()) < 2e-3, (t, b)
     finally:
         tester.release_models()
+
+
+def test_config2_accel18_1024x2048_vs_oracle(demo_cfg, monkeypatch):
+    """BASELINE config 2 at the size the metric is quoted on (the reference validates at 1024x2048 only, README.md:60-71):
+    a key frame and two non-key frames of Accel-18 against the CPU oracle, with the shipped launch-geometry table the
+    bench replays, for the default lowering and for the reference's layer list run one to one (ACCEL_FOLD_LINEAR=0).
+    Tolerance and the verified-discontinuity rule: tests/parity_report.py.  (The oracle needs ~50 s for the three frames
+    on 32 host cores.)"""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 1024, 2048, 3
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 3)
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ACCEL_FOLD_LINEAR", mode)
+        try:
+            outs = demo.run_clip("18", demo_cfg, arg, aux, frames, interval)
+        finally:
+            tester.release_models()
+        check_against_oracle(outs, ref, "config2 accel-18 1024x2048 fold=%s" % mode)
+
+
+def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
+    """BASELINE config 3 at full size: a key and a non-key frame of Accel-101 (ResNet-101 on both branches, feature
+    fusion 4096 -> 2048) against the CPU oracle."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 1024, 2048, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("101", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip("101", demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "101", _oracle_frames(frames, demo_cfg), interval)
+    check_against_oracle(outs, ref, "config3 accel-101 1024x2048")
 
 
 def test_config3_accel101_full_size_properties_1024x2048(demo_cfg):

@@ -51,6 +51,30 @@ def test_clip_parity_without_linear_fold(demo_cfg, version, monkeypatch):
     _check(runner_outs, ref, "accel-%s unfolded" % version)
 
 
+@pytest.mark.parametrize("version", ["18", "101"])
+def test_clip_parity_dcn_stress_offsets_x20(demo_cfg, version):
+    """SURVEY.md 8d "stress set x20": the deformable layers' offset convolutions drawn 20x wider (offsets of 15-30 px, most
+    taps of the outer rings land outside the image), whole clip against the oracle.  The operator is discontinuous at the
+    border, so isolated footprints may deviate -- each one must be VERIFIED against the border taps the oracle recorded
+    (parity_report.flip_windows); everything else meets the usual tolerance."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 256, 512, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params(version, H, W, demo_cfg, offset_std=0.032)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip(version, demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, version, _oracle_frames(frames, demo_cfg), interval)
+    npts = [len(c) for c in ref.critical]
+    print("dcn stress accel-%s: oracle border-tap points per frame %s" % (version, npts))
+    check_against_oracle(outs, ref, "accel-%s dcn-stress" % version, max_windows=6)
+
+
 @pytest.mark.parametrize("version", ["18", "34", "50", "101"])
 def test_clip_parity_128x256(demo_cfg, version):
     from accel_amd import demo

@@ -163,6 +163,67 @@ def test_dcn_border_rule():
     np.testing.assert_allclose(centre(0, -0.25)[:, 0], 0.0)
 
 
+def test_dcn_border_taps_are_found_where_the_operator_is_discontinuous():
+    """ops.deform_border_taps (what the parity checks may excuse deviations with): a tap is reported exactly when its
+    sampling position lies within eps of h = 0, h = H, w = 0 or w = W while the other coordinate is live -- and the
+    operator really jumps there: moving that one offset across the border by 2e-5 changes the output by the border
+    pixel's value, moving any other offset by as much changes nothing measurable."""
+    H = W = 6
+    x = np.arange(1, H * W + 1, dtype=np.float32).reshape(1, 1, H, W)
+    w = np.zeros((1, 1, 3, 3), np.float32)
+    w[0, 0, 0, 1] = 1.0                                   # only tap (i=0, j=1)
+    off = np.full((1, 18, H, W), 0.25, np.float32)        # every tap a quarter pixel inside its cell
+    eps = 1e-4
+    assert len(O.deform_border_taps(H, W, off, (3, 3), 1, 1, 1, eps)) == 0
+    # output pixel (0, 2), tap (0, 1): h_im = 0 - 1 + 0 + off.  off = 1 - 1e-5 puts it 1e-5 below the top border
+    lo, hi = off.copy(), off.copy()
+    lo[0, 2 * 1, 0, 2] = 1.0 - 1e-5
+    hi[0, 2 * 1, 0, 2] = 1.0 + 1e-5
+    for o in (lo, hi):
+        pts = O.deform_border_taps(H, W, o, (3, 3), 1, 1, 1, eps)
+        assert pts.tolist() == [[0, 0, 2]]
+    y_lo, y_hi = O.deform_conv2d(x, lo, w, 1, 1, 1), O.deform_conv2d(x, hi, w, 1, 1, 1)
+    assert y_lo[0, 0, 0, 2] == 0.0 and abs(y_hi[0, 0, 0, 2] - (0.75 * x[0, 0, 0, 2] + 0.25 * x[0, 0, 0, 3])) < 1e-4
+    d = np.abs(y_hi - y_lo)
+    d[0, 0, 0, 2] = 0
+    assert d.max() == 0.0
+    # the far side: h_im = H - 1e-5 is the last row's value, h_im = H is zero; pixel (5, 3), tap (2, 1): h_im = 5 - 1 + 2 + off
+    far = off.copy()
+    far[0, 2 * (2 * 3 + 1), 5, 3] = 0.0 - 1e-5
+    assert O.deform_border_taps(H, W, far, (3, 3), 1, 1, 1, eps).tolist() == [[0, 5, 3]]
+    # a tap far outside in w is dead whatever h does: not reported
+    dead = off.copy()
+    dead[0, 2 * 1, 0, 2] = 1.0 - 1e-5
+    dead[0, 2 * 1 + 1, 0, 2] = 50.0
+    assert len(O.deform_border_taps(H, W, dead, (3, 3), 1, 1, 1, eps)) == 0
+
+
+def test_run_clip_reports_border_points_per_frame(demo_cfg):
+    """graphs.run_clip returns a ClipResult whose .critical lists, frame by frame, the image positions of deformable
+    pixels with a tap at the discontinuity; a non-key frame also carries the points of the key frame it propagates."""
+    from accel_amd.utils import image, synth
+    from oracle import graphs as G
+    Hh, Ww = 64, 128
+    demo_cfg.SCALES[0] = (Hh, Ww)
+    arg, aux = synth.model_params("18", Hh, Ww, demo_cfg, offset_std=0.032)
+    P = dict(arg)
+    P.update(aux)
+    frames = [image.transform(f, demo_cfg.network.PIXEL_MEANS).astype(np.float32) for f in synth.make_clip(Hh, Ww, 2)]
+    old = G.BORDER_EPS
+    G.BORDER_EPS = 1.0           # wide enough that this tiny clip (a 4x8 res5 map) has some
+    try:
+        ref = G.run_clip(P, "18", frames, 2)
+    finally:
+        G.BORDER_EPS = old
+    assert isinstance(ref, G.ClipResult) and len(ref) == 2 and len(ref.critical) == 2
+    assert len(ref.critical[0]) > 0 and all(name.startswith("res5") for name, _, _, _ in ref.critical[0])
+    assert ref.critical[1][:len(ref.critical[0])] == ref.critical[0]
+    assert any(name.startswith("18_res5") for name, _, _, _ in ref.critical[1])
+    for name, n, y, x in ref.critical[1]:
+        assert n == 0 and 0 <= y < Hh and 0 <= x < Ww
+    assert G.RECORD is None
+
+
 def test_argmax_first_max_and_uint8():
     x = np.zeros((1, 19, 2, 3), np.float32)
     x[0, 7] = 1
