@@ -2019,7 +2019,17 @@ extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* rec
     // (2) communication stream: point-to-point to the root, every peer over its own link; the root copies its own block
     HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[s], 0));
     char* recv = static_cast<char*>(recvbuf_or_null);
-    if (c->rank == root) {
+    // ACCEL_GATHER_SELF_SENDRECV=1 (tests on one GPU): the root's own block travels through ncclSend / ncclRecv to itself
+    // inside the group instead of a device copy, so the resolved RCCL entry points, the dtype enum and the group
+    // semantics of this function execute even in a world of one
+    const char* self_sr = getenv("ACCEL_GATHER_SELF_SENDRECV");
+    if (c->rank == root && self_sr && self_sr[0] == '1') {
+        RCCL_TRY(rccl().GroupStart());
+        RCCL_TRY(rccl().Send(c->stage[s], bytes, /*ncclUint8*/ 1, root, c->comm, c->stream));
+        for (int r = 0; r < c->nranks; ++r)
+            RCCL_TRY(rccl().Recv(recv + (size_t)r * bytes, bytes, /*ncclUint8*/ 1, r, c->comm, c->stream));
+        RCCL_TRY(rccl().GroupEnd());
+    } else if (c->rank == root) {
         HIP_TRY(hipMemcpyAsync(recv + (size_t)root * bytes, c->stage[s], bytes, hipMemcpyDeviceToDevice, c->stream));
         if (c->nranks > 1) {
             RCCL_TRY(rccl().GroupStart());

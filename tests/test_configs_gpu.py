@@ -191,12 +191,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("transport", ["cabi", "torch"])
-def test_config4_rccl_gather_on_one_gpu(demo_cfg, transport):
+@pytest.mark.parametrize("transport", ["cabi", "cabi-sendrecv", "torch"])
+def test_config4_rccl_gather_on_one_gpu(demo_cfg, transport, monkeypatch):
     """FrameGather over RCCL with a world of one rank -- through accel_gather_logits of the C ABI ("cabi": libaccel_hip
     + librccl, the default) and through torch.distributed ("torch", the fallback): the gathered tensor of every frame
-    must be byte-identical to the model's logits / labels buffer, across more frames than staging slots."""
+    must be byte-identical to the model's logits / labels buffer, across more frames than staging slots.
+    "cabi-sendrecv": ACCEL_GATHER_SELF_SENDRECV=1 routes the root's own block through ncclGroupStart / ncclSend-to-self /
+    ncclRecv-from-self / ncclGroupEnd, so the dlsym'd RCCL entry points, the dtype enum and the group semantics of the
+    N > 1 path execute on hardware even though only one GPU is here."""
     import torch
+    if transport == "cabi-sendrecv":
+        monkeypatch.setenv("ACCEL_GATHER_SELF_SENDRECV", "1")
+        transport = "cabi"
     import torch.distributed as dist
     from accel_amd import demo, dist as adist
     from accel_amd.core import tester

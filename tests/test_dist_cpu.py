@@ -89,3 +89,22 @@ def test_gather_logits_world2_gloo():
     seen0 = res[0][0]
     assert seen0 == [[1.0 + t, 101.0 + t] for t in range(5)]     # rank order preserved, frame t from every rank
     assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4, 5]
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment must start the two ranks itself (under
+    torch.distributed.run on 127.0.0.1) -- never run one rank and report it as two.  --launch-check stops every rank
+    before any GPU work, so the launch path is testable here."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in recs) == [0, 1] and all(r["world"] == 2 and r["self_launched"] for r in recs)
+    # a launcher that started another number of ranks than --gpus asks for is refused
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
