@@ -373,6 +373,29 @@ static void pack_bf16x3(const std::vector<float>& packed, int classes, int rows,
             }
 }
 
+// The same three planes in MFMA fragment order for conv_b3r.hip: [class][K step][half step][row][16] -- the 16 bytes lane
+// (row, half) feeds to one v_mfma_f32_32x32x16_bf16 are contiguous (k = 32*step + 16*halfstep + 8*half .. +8), a
+// wavefront's fragment fetch is one contiguous kilobyte.  Two K steps of slack: the kernel prefetches past the end.
+static void pack_bf16x3r(const std::vector<float>& packed, int classes, int rows, int K_pad, std::vector<uint16_t>& out, size_t plane)
+{
+    const int steps = K_pad / 32;
+    out.assign(3 * plane, 0);
+    for (int c = 0; c < classes; ++c)
+        for (int n = 0; n < rows; ++n)
+            for (int k = 0; k < K_pad; ++k) {
+                float r = packed[((size_t)c * rows + n) * K_pad + k];
+                const int ks = k / 32, kb = (k >> 4) & 1, kk = k & 15;
+                const size_t dst = ((((size_t)c * steps + ks) * 2 + kb) * rows + n) * 16 + kk;
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint32_t u; memcpy(&u, &r, 4);
+                    u &= 0xFFFF0000u;
+                    out[pl * plane + dst] = (uint16_t)(u >> 16);
+                    float t; memcpy(&t, &u, 4);
+                    r -= t;
+                }
+            }
+}
+
 // conv weights (Cout, Cin, kh, kw) -> [rows][K_pad], k = (ky*kw + kx)*cin_pad + ci
 static void pack_conv_w(const HostParam& w, int cin_pad, int rows, int K_pad, std::vector<float>& out)
 {
@@ -495,13 +518,21 @@ static int finalize_conv(accel_plan* p, Op& op)
         // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_BF16X3=0 withholds it)
         const char* be = getenv("ACCEL_BF16X3");
         const int ft = (int)kv_int(kv, "tile", -1);
-        const bool forced = ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 6;
+        const bool forced = (ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 12) || (ft >= 90 && ft <= 96);
         if (!c.f16 && c.Cin % 4 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
             std::vector<uint16_t> pb;
             pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
             void* d3 = nullptr;
             if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
             c.wb3 = d3;
+            const char* re_ = getenv("ACCEL_B3R");
+            const bool forced_r = (ft >= CONV_TILE_B3R && ft < CONV_TILE_B3R + 6) || (ft >= 90 && ft <= 96);
+            if (!(re_ && re_[0] == '0') || forced_r) {      // the fragment-ordered copy for the second-generation kernel
+                pack_bf16x3r(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
+                void* d4 = nullptr;
+                if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d4))) return rc;
+                c.wb3r = d4;
+            }
         } else if (forced) {
             return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with more than "
                                        "4 output channels only", op.name.c_str());
@@ -920,7 +951,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-4"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-5"
 
 static std::string lib_dir()
 {
@@ -1032,10 +1063,12 @@ static int autotune_plan(accel_plan* p)
             if (c.wws) cs.push_back({CONV_TILE_WS, 0, 0});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
-                                        CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5};
+                                        CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
+                                        CONV_TILE_B3R, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && !nb3) continue;
+                if (t >= CONV_TILE_B3R && !c.wb3r) continue;
                 if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 if (c.f16 && !(t <= 3 || t == 10)) continue;

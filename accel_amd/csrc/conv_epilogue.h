@@ -1,0 +1,115 @@
+// Fused epilogue shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_b3r.hip): split-K partial store
+// or scale/shift -> +residual -> activation -> store (+ dual output), from 32x32 MFMA accumulators.
+#pragma once
+#include "kernels.h"
+#include "conv_common.h"
+
+// Shared tail of both conv kernels: split-K partial store or the fused epilogue
+// (scale/shift -> +residual -> activation -> store, optional dual output).
+template <int MI, int NI, int WGN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
+                                              int lane, int py, int px, int HoWo)
+{
+    // ---- output coordinates of this lane's 16*MI accumulator rows ------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31 (-> co), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
+
+    // ---- split-K: raw partial sums to the workspace [split][class][M][Cout_store] ----
+    if (p.ksplit > 1) {
+        const size_t slab = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)p.M * p.Cout_store;
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.ws + slab, (unsigned)((size_t)p.M * p.Cout_store * 4));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int co = n0 + (wn * NI + j) * 32 + (lane & 31);
+            const bool cok = co < p.Cout_store;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = rbase + i * 32 + (e & 3) + 8 * (e >> 2);
+                    buf_store1(wr, (cok && m < p.M) ? (unsigned)((m * p.Cout_store + co) * 4) : OOB, acc[i][j][e]);
+                }
+        }
+        return;
+    }
+
+    // ---- fused epilogue: scale/shift (+residual) -> activation -> store (+ dual output) ----
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t y2r = make_rsrc(p.y2 ? p.y2 : p.y, p.y2 ? p.y2_bytes : 0u);
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    auto pixel_of = [&](int m) -> unsigned {      // NHWC pixel index of GEMM row m, OOB past M
+        if (m >= p.M) return OOB;
+        if (!p.deconv2x) return (unsigned)m;
+        int n, rem, oy, ox;
+        divmod_small(m, HoWo, inv_howo, n, rem);
+        divmod_small(rem, p.Wo, inv_wo, oy, ox);
+        const int yy = 2 * oy + py, xx = 2 * ox + px;
+        if (yy >= p.yH || xx >= p.yW) return OOB;      // output cropped to 2h-1 / 2w-1 (Crop after a pad-0 deconvolution)
+        return (unsigned)((n * p.yH + yy) * p.yW + xx);
+    };
+    // Vector-memory operations retire IN ORDER through one counter: a residual load issued behind an output store cannot
+    // be consumed before that store has been acknowledged.  Loading the residual group by group between the stores
+    // (the obvious loop) therefore serialises 16*MI*NI/4 store round trips per wavefront -- measured as 4-11 us of
+    // epilogue on 42 us residual layers.  So: every per-channel constant and EVERY residual value is fetched before the
+    // first store is issued; after that the epilogue only computes and stores.
+    float sc[NI], sf[NI], sc2[NI], sf2[NI];
+    bool cok[NI];
+    int co[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        co[j] = n0 + (wn * NI + j) * 32 + (lane & 31);
+        cok[j] = co[j] < p.Cout_store;
+        const int cc = cok[j] ? co[j] : 0;
+        sc[j] = p.scale[cc]; sf[j] = p.shift[cc];
+        sc2[j] = p.y2 ? p.scale2[cc] : 1.f; sf2[j] = p.y2 ? p.shift2[cc] : 0.f;
+    }
+    if (p.res) {
+        float rv[MI][NI][16];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
+                    rv[i][j][e] = buf_load1(rr, (cok[j] && px_ != OOB) ? (px_ * p.resCs + co[j]) * 4u : OOB);
+                }
+        // accumulators become acc*scale + shift + residual here, so the store loop below is shared with the plain case
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][j][e];
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {          // 4 rows at a time keeps the live set small
+                unsigned pix[4];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned px_ = pixel_of(rbase + i * 32 + e + 8 * h);
+                    pix[e] = cok[j] ? px_ : OOB;
+                    v[e] = p.res ? acc[i][j][h * 4 + e] : acc[i][j][h * 4 + e] * sc[j] + sf[j];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                    else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                    buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co[j]) * 4u : OOB, v[e]);
+                }
+                if (p.y2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, fmaxf(v[e] * sc2[j] + sf2[j], 0.f));
+                }
+            }
+        }
+    }
+}
+

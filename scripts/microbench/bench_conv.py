@@ -47,6 +47,24 @@ if __import__('os').environ.get("SHORTK"):   # short-K residual 1x1 layers at 8 
               ("res3_2c 1x1 128-512 +res x8", 128, 512, 1024, 256, 1, 1, 0, 1, 1, "conv"),
               ("res2_2c 1x1 64-256 +res x8", 64, 256, 2048, 512, 1, 1, 0, 1, 1, "conv"),
               ("res4_2a 1x1 1024-256 x8", 1024, 256, 512, 128, 1, 1, 0, 1, 0, "conv")]
+if __import__('os').environ.get("B8"):       # the layers that carry the 8-clips-per-call step (rows of the 8 images stacked)
+    SHAPES = [("fc6 1x1 2048-1024 x8", 2048, 1024, 512, 128, 1, 1, 0, 1, 0, "conv"),
+              ("res5a_1 1x1 1024-2048 x8", 1024, 2048, 512, 128, 1, 1, 0, 1, 0, "conv"),
+              ("res5 2b cols 4608-512 x8", 4608, 512, 512, 128, 1, 1, 0, 1, 0, "conv"),
+              ("res5 2c 1x1 512-2048 +res x8", 512, 2048, 512, 128, 1, 1, 0, 1, 1, "conv"),
+              ("res5 2a 1x1 2048-512 x8", 2048, 512, 512, 128, 1, 1, 0, 1, 0, "conv"),
+              ("res4_2a 1x1 1024-256 x8", 1024, 256, 512, 128, 1, 1, 0, 1, 0, "conv"),
+              ("res4_2c 1x1 256-1024 +res x8", 256, 1024, 512, 128, 1, 1, 0, 1, 1, "conv"),
+              ("res4_2b 3x3 256-256 x8", 256, 256, 512, 128, 3, 1, 1, 1, 0, "conv"),
+              ("res3_2a 1x1 512-128 x8", 512, 128, 1024, 256, 1, 1, 0, 1, 0, "conv"),
+              ("res3_2b 3x3 128-128 x8", 128, 128, 1024, 256, 3, 1, 1, 1, 0, "conv"),
+              ("res3_2c 1x1 128-512 +res x8", 128, 512, 1024, 256, 1, 1, 0, 1, 1, "conv"),
+              ("res2_2a 1x1 256-64 x8", 256, 64, 2048, 512, 1, 1, 0, 1, 0, "conv"),
+              ("feat_up*fc6 deconv 512-1024 @32x64 x8", 512, 1024, 256, 64, 4, 2, 1, 1, 0, "deconv2x"),
+              ("flow conv2 5x5 64-128 s2 x8", 64, 128, 2048, 512, 5, 2, 2, 1, 0, "conv"),
+              ("flow conv3 5x5 128-256 s2 x8", 128, 256, 1024, 256, 5, 2, 2, 1, 0, "conv"),
+              ("r18 s2 3x3 64-128 s2 x8", 64, 128, 2048, 512, 3, 2, 1, 1, 0, "conv"),
+              ("r18 res5a 2b cols 4608-512 @32x64 x8", 4608, 512, 256, 64, 1, 1, 0, 1, 0, "conv")]
 if __import__('os').environ.get("KSWEEP"):   # time vs K at fixed M, N: slope = steady-state rate, intercept = fixed cost per launch
     SHAPES = [("K=%d N=256 M=8192" % k, k, 256, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 64, 128, 256, 512, 1024, 2304, 4608, 8192)]
     SHAPES += [("K=%d N=1024 M=8192" % k, k, 1024, 64, 128, 1, 1, 0, 1, 0, "conv") for k in (32, 256, 1024, 4096)]

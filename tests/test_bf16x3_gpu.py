@@ -47,7 +47,7 @@ def test_conv_bf16x3_every_geometry_within_the_fp32_tolerance(ctx, b3_mode, tile
     assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))     # the fp32 operator bar of test_ops_gpu
 
 
-@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74, 75])
+@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74, 75, 76, 79, 80, 81])
 def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
     """In fp32 mode the kernel is offered to the autotuner as launch geometries 70-74 of the same convolution."""
     from accel_amd.runtime import AccelError
@@ -62,6 +62,43 @@ def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
         assert float(np.abs(ctx.conv2d(xc, wc, None, 1, 1, 1, tile=tile) - refc).max()) <= 1e-4 * max(1.0, float(np.abs(refc).max())), C
     with pytest.raises(AccelError, match="bf16x3"):
         ctx.conv2d(rnd(26, 1, 16, 16, 16), rnd(27, 2, 16, 3, 3), None, 1, 1, 1, tile=tile)      # 2 output channels: the strip kernel's layer
+
+
+@pytest.mark.parametrize("tile", [74, 76, 79, 80, 81])
+def test_bf16x3_register_weight_kernel_deconv_splitk_and_batch(ctx, tile):
+    """conv_b3r.hip (76, 79, 80, 81: weight fragments global -> VGPR in MFMA order, pixel tile double-buffered in LDS)
+    on what the convolution test above does not reach: the four parity classes of the 4x4/2 deconvolution (class-major
+    planes), split-K (small pixel count, long reduction: partial sums + reduce kernel), a batch of images in one GEMM,
+    and an odd number of K steps.  74 (the first-generation kernel) runs the same cases as the control."""
+    from accel_amd import runtime
+    # deconvolution 4x4/2 through a one-op plan with the geometry forced
+    cin, cout, H, W = 96, 160, 9, 13
+    x, w = rnd(40, cin, H, W), rnd(41, cin, cout, 4, 4, scale=0.05)
+    m = runtime.Model(ctx)
+    try:
+        m.set_param("w_weight", w)
+        al = lambda b: (b + 255) // 256 * 256
+        o_y = al(H * W * cin * 4)
+        t = "option graph=0\narena bytes=%d\npbuf name=x bytes=%d\npbuf name=y bytes=%d\n" % (o_y + al(4 * H * W * cout * 4), cin * H * W * 4, cout * 4 * H * W * 4)
+        t += "import_nchw src=x:0:%d:%d:%d:%d dst=A:0:%d:%d:%d:%d\n" % (cin, cin, H, W, cin, cin, H, W)
+        t += "conv name=c in=A:0:%d:%d:%d:%d out=A:%d:%d:%d:%d:%d w=w_weight act=0 cin=%d cout=%d mode=deconv2x tile=%d\n" % (
+            cin, cin, H, W, o_y, cout, cout, 2 * H, 2 * W, cin, cout, tile)
+        t += "export_nchw src=A:%d:%d:%d:%d:%d dst=y:0:%d:%d:%d:%d\n" % (o_y, cout, cout, 2 * H, 2 * W, cout, cout, 2 * H, 2 * W)
+        plan = m.add_plan("p", t)
+        m.write("x", x)
+        plan.finalize()
+        plan.run()
+        got = m.read("y", (1, cout, 2 * H, 2 * W))
+    finally:
+        m.close()
+    ref = O.deconv2d(x[None], w, None, 2, 1)
+    assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    # split-K: 8 x 16 pixels, K = 9 * 512; batch of 3 images; K = 5 * 96 = 15 K steps (odd)
+    for (N, C, K, Hh, Ww, k, s_, p_, d_) in ((1, 512, 136, 8, 16, 3, 1, 1, 1), (3, 64, 72, 20, 28, 3, 1, 2, 2), (2, 96, 64, 12, 10, 5, 2, 2, 1)):
+        xx, ww, bb = rnd(42, N, C, Hh, Ww), rnd(43, K, C, k, k, scale=(2.0 / (C * k * k)) ** 0.5), rnd(44, K)
+        ref = O.conv2d(xx, ww, bb, s_, p_, d_)
+        got = ctx.conv2d(xx, ww, bb, s_, p_, d_, tile=tile)
+        assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max())), (N, C, K)
 
 
 @pytest.mark.parametrize("C,K,H,W,k,s,p,d", CASES)
