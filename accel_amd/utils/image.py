@@ -2,13 +2,19 @@
 import numpy as np
 
 
-def _resize_bilinear(im, out_h, out_w):
-    """cv2.resize(..., INTER_LINEAR) geometry: half-pixel centres, edge clamp."""
+def _resize_bilinear(im, out_h, out_w, scale_y=None, scale_x=None):
+    """cv2.resize(..., INTER_LINEAR) geometry: half-pixel centres, source coordinate (dst + 0.5) * scale - 0.5 clamped to the
+    image, where scale = 1 / fx when the caller gave fx (cv2 keeps the REQUESTED factor, not in / out, when dsize is derived
+    from it -- lib/utils/image.py:209 calls it that way) and in / out otherwise.  Arithmetic in float64 with one final
+    rounding; cv2's uint8 path uses 11-bit fixed-point weights and may differ by one grey level.  (The BASELINE path never
+    gets here: 1024x2048 frames at SCALES (1024, 2048) have scale exactly 1.)"""
     h, w = im.shape[:2]
     if (h, w) == (out_h, out_w):
         return im
-    ys = np.clip((np.arange(out_h) + 0.5) * h / out_h - 0.5, 0, h - 1)
-    xs = np.clip((np.arange(out_w) + 0.5) * w / out_w - 0.5, 0, w - 1)
+    sy = float(h) / out_h if scale_y is None else scale_y
+    sx = float(w) / out_w if scale_x is None else scale_x
+    ys = np.clip((np.arange(out_h) + 0.5) * sy - 0.5, 0, h - 1)
+    xs = np.clip((np.arange(out_w) + 0.5) * sx - 0.5, 0, w - 1)
     y0 = np.floor(ys).astype(int)
     x0 = np.floor(xs).astype(int)
     y1 = np.minimum(y0 + 1, h - 1)
@@ -35,7 +41,7 @@ def resize(im, target_size, max_size, stride=0):
     if np.round(im_scale * im_size_max) > max_size:
         im_scale = float(max_size) / float(im_size_max)
     if im_scale != 1.0:
-        im = _resize_bilinear(im, int(round(im_shape[0] * im_scale)), int(round(im_shape[1] * im_scale)))
+        im = _resize_bilinear(im, int(round(im_shape[0] * im_scale)), int(round(im_shape[1] * im_scale)), 1.0 / im_scale, 1.0 / im_scale)
     if stride == 0:
         return im, im_scale
     im_height = int(np.ceil(im.shape[0] / float(stride)) * stride)

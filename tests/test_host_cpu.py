@@ -649,3 +649,32 @@ def test_shipped_tune_table_loads():
     assert all(len(l.split()) == 19 for l in lines[1:]) and len(lines) > 100
     replayed, timed, shipped = runtime.tune_stats()
     assert shipped == len(lines) - 1 and timed == 0
+
+
+_REF_CFGS = "/root/reference/experiments/dff_deeplab/cfgs"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_CFGS), reason="the reference checkout is only present in the build container")
+def test_reference_experiment_configs_drop_in_unchanged():
+    """experiments/dff_deeplab/cfgs/*.yaml load through config.update_config unchanged, name a symbol class this package
+    has, and both test graphs of it build and lower (the harness's `eval(config.symbol + '.' + config.symbol)()`,
+    demo.py:127-132).  Skipped where /root/reference does not exist (the GPU box)."""
+    import glob
+    from accel_amd import lower, symbols
+    from accel_amd.config.config import config, reset_config, update_config
+    files = sorted(glob.glob(os.path.join(_REF_CFGS, "*.yaml")))
+    assert len(files) >= 5
+    for f in files:
+        reset_config()
+        update_config(f)
+        name = config.symbol or "accel_18"      # the demo yaml names no symbol: demo.py picks accel_<version> (demo.py:127)
+        inst = getattr(getattr(symbols, name), name)()
+        key, cur = inst.get_key_test_symbol(config), inst.get_cur_test_symbol(config)
+        assert key.list_outputs()[-1] == "croped_score_output" and "warping_feat_output" in cur.list_outputs()
+        H, W = 128, 256
+        for sym, feat in ((key, (1, 2048, 1, 1)), (cur, (1, 2048, H // 16, W // 16))):
+            shapes = {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": feat}
+            shapes = {k: v for k, v in shapes.items() if k in sym.list_arguments()}
+            text, lw = lower.lower(sym, shapes)
+            assert lw.total_flops > 0 and "score_tail" in text
+    reset_config()

@@ -225,3 +225,36 @@ def test_dcn_oracle_vs_grid_sample_also_outside_where_rules_agree():
     ref = _dcn_by_grid_sample(x, off, w, 1, 1, 1, dg)
     # taps 1..7 except the centre sit on integer positions; the rim rows/cols of taps hitting -1 or H are zero in both
     assert float(np.abs(got - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# lib/utils/image.py:194-222 resize = cv2.resize(fx, fy, INTER_LINEAR): hand-computed cases for non-identity scales
+# ---------------------------------------------------------------------------------------------------------------
+def test_resize_inter_linear_hand_computed_cases():
+    from accel_amd.utils.image import resize
+    # x2: source coordinate (d + 0.5) / 2 - 0.5 = -0.25, 0.25, 0.75, 1.25 -> clamped 0 | 0.25 | 0.75 | 1
+    im = np.array([[[0.0], [100.0]], [[200.0], [255.0]]])
+    out, sc = resize(im, 4, 4)
+    assert sc == 2.0 and out.shape == (4, 4, 1)
+    np.testing.assert_allclose(out[0, :, 0], [0.0, 25.0, 75.0, 100.0])
+    np.testing.assert_allclose(out[3, :, 0], [200.0, 213.75, 241.25, 255.0])
+    np.testing.assert_allclose(out[1, :, 0], 0.75 * out[0, :, 0] + 0.25 * out[3, :, 0])
+    # x0.5: (d + 0.5) * 2 - 0.5 = 0.5, 2.5 -> the mean of pixels (0,1) and (2,3) in each direction
+    im4 = np.arange(16, dtype=np.float64).reshape(4, 4, 1)
+    half, sc = resize(im4, 2, 2)
+    assert sc == 0.5
+    np.testing.assert_allclose(half[:, :, 0], [[2.5, 4.5], [10.5, 12.5]])
+    # fx = 0.7 on 10 columns: dsize = round(7.0) = 7 and the source step is 1 / 0.7 (the requested factor); on 3 columns
+    # dsize = round(2.1) = 2 while in / out = 1.5: cv2 keeps 1 / 0.7, so d = 0, 1 read x = 0.2143, 1.6429
+    row = np.array([[[0.0], [10.0], [40.0]]])
+    r, sc = resize(np.repeat(row, 3, axis=0), 2.1, 2.1)      # target / short side = 0.7
+    assert abs(sc - 0.7) < 1e-12 and r.shape == (2, 2, 1)
+    x = (np.arange(2) + 0.5) / 0.7 - 0.5
+    exp = [0.0 * (1 - x[0]) + 10.0 * x[0], 10.0 * (2 - x[1]) + 40.0 * (x[1] - 1)]
+    np.testing.assert_allclose(r[0, :, 0], exp)
+    # uint8 stays uint8, rounded once
+    u8, _ = resize(np.array([[[0], [101]], [[0], [101]]], np.uint8), 4, 4)
+    assert u8.dtype == np.uint8 and u8[0, :, 0].tolist() == [0, 25, 76, 101]
+    # stride padding: zeros to the next multiple (image.py:213-220)
+    pad, _ = resize(np.ones((5, 7, 3)), 5, 7, stride=4)
+    assert pad.shape == (8, 8, 3) and pad[:5, :7].min() == 1 and pad[5:].max() == 0 and pad[:, 7:].max() == 0
