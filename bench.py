@@ -260,7 +260,8 @@ class Workload(object):
         for k, v in sorted(fam.items()):
             alg = v[2] / (v[1] * 1e-3) / 1e12 if v[1] else 0.0
             d = {"launches_per_step": int(v[0]), "avg_launch_us": round(1e3 * v[1] / v[0], 2), "ms_per_step": round(v[1], 3),
-                 "algorithmic_tflops": round(alg, 2), "hbm_gbps_algorithmic": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[1] else 0.0}
+                 "algorithmic_tflops": round(alg, 2), "hbm_gbps_algorithmic": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[1] else 0.0,
+                 "algorithmic_bytes_per_launch": round(v[3] / v[0]), "algorithmic_gflop_per_launch": round(v[2] / v[0] / 1e9, 3)}
             if k in pipe:
                 mul, pk, what = pipe[k]
                 d.update({"executed_tflops": round(mul * alg, 1), "executed_peak_tflops": pk, "executed_frac": round(mul * alg / pk, 4), "pipe": what})
@@ -278,7 +279,8 @@ class Workload(object):
                                  "their HIP-event durations, against the dense peak of the pipe it runs on (%s)"
                                  % (dom, D["ms_per_step"], ms, D["pipe"]),
                 "avg_launch_us": D["avg_launch_us"], "launches_per_step": D["launches_per_step"],
-                "algorithmic_tflops": D["algorithmic_tflops"],
+                "algorithmic_tflops": D["algorithmic_tflops"], "algorithmic_bytes_per_launch": D["algorithmic_bytes_per_launch"],
+                "algorithmic_gflop_per_launch": D["algorithmic_gflop_per_launch"],
                 "all_conv": {"frac": round(ideal_ms / matrix_ms, 4) if matrix_ms else None,
                              "what": "time-weighted over every matrix-core convolution launch of a step: sum(executed flop_i / peak_i) / sum(t_i)",
                              "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
@@ -298,8 +300,8 @@ class Workload(object):
 
 
 def _pmc_traffic(version, H, W, interval, dtype, B):
-    """HBM bytes per conv launch from the committed PMC passes of this same command (counters cannot be read from
-    inside the process): only reported for the workload they were collected on."""
+    """HBM bytes per launch of the DOMINANT convolution family (the bf16x3 implicit GEMM) from the committed PMC passes of
+    this same command (counters cannot be read from inside the process): only reported for the workload they were collected on."""
     import glob
     files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_traffic.json")))
     if not files or not (version == "18" and (H, W) == (1024, 2048) and interval == 5 and dtype == "f32"):
@@ -308,8 +310,10 @@ def _pmc_traffic(version, H, W, interval, dtype, B):
         tr = json.load(f)
     if int(tr.get("batch", 1)) != B:
         return None, None
-    return (round(tr["read_bytes_per_launch"] + tr["write_bytes_per_launch"]),
-            "from the committed PMC passes (%s): %s" % (os.path.relpath(files[-1], HERE), tr["method"]))
+    d = tr.get("dominant", tr)
+    return (round(d["read_bytes_per_launch"] + d["write_bytes_per_launch"]),
+            "HBM read + write bytes per launch of %s from the committed PMC passes (%s): %s"
+            % (" / ".join(d.get("kernels", ["the convolution kernels"])), os.path.relpath(files[-1], HERE), tr["method"]))
 
 
 def _run(a):
@@ -492,6 +496,23 @@ def _run(a):
                 sec["accel18_batch%d_fp32_mfma_only" % B] = {"error": repr(e)}
             finally:
                 os.environ.pop("ACCEL_BF16X3", None)
+        # BASELINE config 5 (reduced precision, never the headline): Accel-50, fp16-MFMA convolutions (operands rounded to half
+        # by the loader, fp32 storage + accumulate), 2048x4096, key-frame interval 10, one clip
+        try:
+            os.environ["ACCEL_CONV_DTYPE"] = "f16"
+            w5 = Workload("50", 1, 2048, 4096, 10, local_rank, rank, config)
+            el = w5.timed(2, 1)
+            rf = w5.conv_roofline("f16")
+            sec["accel50_f16_2048x4096_kf10"] = {
+                "value": round(2 * 10 / el, 2), "unit": "frames/s", "clips_per_call": 1,
+                "what": "BASELINE config 5 on one GPU: Accel-50, fp16-MFMA convolutions with fp32 storage / accumulation (REDUCED precision: "
+                        "error against the fp32 oracle 4-5 % of the logit range at the worst pixel, tests/test_f16_gpu.py), 2048x4096, kf=10",
+                "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_fp16_peak": rf["all_conv"]["frac"]}
+            w5.close()
+        except Exception as e:
+            sec["accel50_f16_2048x4096_kf10"] = {"error": repr(e)}
+        finally:
+            os.environ["ACCEL_CONV_DTYPE"] = a.dtype
         out["secondary"] = sec
     else:
         wl.close()

@@ -15,4 +15,5 @@ for v in 34 50; do
   python bench.py --version $v --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
 done
 python bench.py --size 512x1024 --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
+python bench.py --version 50 --dtype f16 --size 2048x4096 --interval 10 --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err    # config 5
 wc -l $ACCEL_TUNE_CACHE

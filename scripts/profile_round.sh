@@ -2,7 +2,7 @@
 # Round profile recipe (run on the GPU box through gpurun; outputs under gpurun_out/, summaries are then copied
 # to profiles/ by hand):  bash scripts/profile_round.sh r01
 # 1. plain bench (headline + secondaries)
-# 2. rocprofv3 --kernel-trace --stats of the same command (two-stream default, then ACCEL_MULTI_STREAM=0)
+# 2. rocprofv3 --kernel-trace --stats of the same command (plans run on one stream: per-launch durations are exact)
 # 3. three separate --pmc passes (SQ / FETCH_SIZE / WRITE_SIZE), never combined with the trace domains
 # 4. per-op HIP-event timings of both plans
 set -u
@@ -15,7 +15,6 @@ python bench.py > $OUT/bench_${R}_final.json 2> $OUT/bench_${R}_final.err
 cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --secondary none"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$R -o bench --output-format csv -- $B > $OUT/prof_${R}_bench.json 2>/dev/null
-ACCEL_MULTI_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/prof_${R}_1s -o bench --output-format csv -- $B > $OUT/prof_${R}_1s_bench.json 2>/dev/null
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/prof_${R}_pmc1 -o bench --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_${R}_pmc2 -o bench --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_${R}_pmc3 -o bench --output-format csv -- $B > /dev/null 2>&1

@@ -63,19 +63,26 @@ def main():
 
 
     if len(sys.argv) > 5:
-        fams = ("conv_igemm_f32_kernel", "conv_wino_f32_kernel", "conv_stem_f32_kernel", "conv1x1_ws_kernel", "conv_narrow_kernel", "conv_narrow3x3_kernel", "conv_igemm_f16_kernel")
-        fam = "convolution kernels: " + ", ".join(fams)
-        is_conv = lambda k: any(f in k for f in fams)
-        rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if is_conv(k)) * 2 * 1024
-        nr = sum(n for k, n in nf.items() if is_conv(k))
-        ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if is_conv(k)) * 1024
-        nwr = sum(n for k, n in nw.items() if is_conv(k))
-        extra = dict(a.split("=", 1) for a in sys.argv[6:] if "=" in a)      # e.g. batch=4: the workload the passes ran
-        json.dump({"kernel": fam + " (all tile variants)", "batch": int(extra.get("batch", 1)), "read_bytes_per_launch": rd / max(nr, 1),
-                   "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr,
-                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 8 "
-                             "--warmup 2 --no-cpu-baseline --secondary none`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "
-                             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"},
+        extra = dict(a.split("=", 1) for a in sys.argv[6:] if "=" in a)      # e.g. batch=8: the workload the passes ran
+        method = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --steps 8 "
+                  "--warmup 2 --no-cpu-baseline --secondary none`; KiB units; gfx950 correction: read bytes = 2 x FETCH_SIZE "
+                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated")
+
+        def traffic(fams):
+            sel = lambda k: any(f in k for f in fams)
+            rd = sum(v.get("FETCH_SIZE", 0) for k, v in fe.items() if sel(k)) * 2 * 1024
+            nr = sum(n for k, n in nf.items() if sel(k))
+            ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if sel(k)) * 1024
+            nwr = sum(n for k, n in nw.items() if sel(k))
+            return {"kernels": list(fams), "read_bytes_per_launch": rd / max(nr, 1), "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr}
+        conv = ("conv_igemm_f32_kernel", "conv_igemm_b3_kernel", "conv_b3r_kernel", "conv_wino_f32_kernel", "conv_stem_f32_kernel", "conv1x1_ws_kernel",
+                "conv_narrow_kernel", "conv_narrow3x3_kernel", "conv_igemm_f16_kernel")
+        dom = traffic(("conv_igemm_b3_kernel", "conv_b3r_kernel"))      # the bf16x3 implicit-GEMM family: bench.py's roofline.kernel
+        allc = traffic(conv)
+        json.dump({"batch": int(extra.get("batch", 1)), "method": method, "dominant": dom, "all_conv": allc,
+                   # (kept for readers of the round-1/2 files)
+                   "kernel": "convolution kernels (all families)", "read_bytes_per_launch": allc["read_bytes_per_launch"],
+                   "write_bytes_per_launch": allc["write_bytes_per_launch"], "launches_sampled": allc["launches_sampled"]},
                   open(sys.argv[5], "w"), indent=1)
 
 

@@ -68,3 +68,40 @@ def test_clip_f16_close_to_fp32_oracle(demo_cfg, f16_mode):
         assert float(np.abs(lg - rlg).max()) <= 0.1 * scale, "frame %d" % t
         assert float(np.abs(lg - rlg).mean()) <= 1e-2 * scale, "frame %d" % t
         assert float((lab != rlab[0]).mean()) < 1e-2
+
+
+def test_clip_f16_matches_the_oracle_on_half_rounded_operands_512x1024(demo_cfg, f16_mode, monkeypatch):
+    """The reduced-precision mode against ITS OWN specification: oracle.graphs with ROUND_F16 rounds the operands of the
+    same layers the HIP loader rounds (Cin % 8 == 0, more than 4 output channels; deformable layers: the sampled columns)
+    and keeps products and sums in fp32.  Accel-50 (BASELINE config 5's model), 512x1024, key + non-key frame, the
+    reference's layer list one to one.  What remains between the two is fp32 summation order plus the occasional operand
+    that rounds to the neighbouring half because of it -- an order of magnitude below the distance to the fp32 result."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    monkeypatch.setenv("ACCEL_FOLD_LINEAR", "0")
+    H, W, interval = 512, 1024, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("50", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip("50", demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    fr = [image.transform(f, demo_cfg.network.PIXEL_MEANS).astype(np.float32) for f in frames]
+    G.ROUND_F16 = True
+    try:
+        ref16 = G.run_clip(P, "50", fr, interval)
+    finally:
+        G.ROUND_F16 = False
+    ref32 = G.run_clip(P, "50", fr, interval)
+    for t, ((lg, lab), (r16, l16), (r32, l32)) in enumerate(zip(outs, ref16, ref32)):
+        scale = max(1.0, float(np.abs(r32).max()))
+        e16, e32 = float(np.abs(lg - r16).max()) / scale, float(np.abs(lg - r32).max()) / scale
+        m16, m32 = float(np.abs(lg - r16).mean()) / scale, float(np.abs(lg - r32).mean()) / scale
+        print("f16 mode frame %d: vs half-rounded oracle max %.2e mean %.2e | vs fp32 oracle max %.2e mean %.2e (of the logit range); "
+              "labels differing %.4f %% / %.4f %%" % (t, e16, m16, e32, m32, 100 * float((lab != l16[0]).mean()), 100 * float((lab != l32[0]).mean())))
+        assert e16 <= 1e-2 and m16 <= 1e-3, "frame %d" % t
+        assert m16 <= 0.5 * m32, "frame %d: no closer to its own specification than to the fp32 result" % t
+        assert float((lab != l16[0]).mean()) < 5e-3
