@@ -1051,7 +1051,10 @@ static int autotune_plan(accel_plan* p)
         if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
         else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
-            if (c.wu) {
+            // (a layer that runs in fp16-MFMA mode stays on the fp16 kernel: "operands of every convolution with Cin % 8 == 0 and
+            // more than 4 output channels are rounded to half" is then the exact specification of the mode, which the oracle
+            // restates -- oracle/graphs.py ROUND_F16 -- instead of depending on what the tuner happened to pick)
+            if (c.wu && !c.f16) {
                 cs.push_back({CONV_TILE_WINO, 0, 0});
                 ConvParams q = c;
                 const size_t base = conv_apply(q, CONV_TILE_WINO, 0, 0);
@@ -1059,8 +1062,8 @@ static int autotune_plan(accel_plan* p)
                 if (conv_apply(q, CONV_TILE_WINO, 1024, 0) && q.ksplit != ks0) cs.push_back({CONV_TILE_WINO, 1024, 0});
                 if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
             }
-            if (c.wstem) cs.push_back({CONV_TILE_STEM, 0, 0});
-            if (c.wws) cs.push_back({CONV_TILE_WS, 0, 0});
+            if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
+            if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
