@@ -1,4 +1,4 @@
-// bf16x3 implicit GEMM, second generation ("b3r", launch geometries 76 / 79 / 80 / 81): fp32 values on the bf16 matrix cores as in
+// bf16x3 implicit GEMM, second generation ("b3r", launch geometries 76 / 77 / 79 / 80 / 81): fp32 values on the bf16 matrix cores as in
 // conv_igemm_b3_kernel (each operand split EXACTLY into three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per
 // multiply-add, fp32 accumulate -- see conv_igemm.hip), with the staging reorganised around what bounded that kernel.
 //
@@ -259,6 +259,7 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
 {
     switch (tile) {
         case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4>(p, st);
+        case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2>(p, st);       // 64-channel layers (res2, the ResNet-18 trunk's first stage)
         case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4>(p, st);
         case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8>(p, st);      // every wavefront owns 32 columns: no weight fragment is fetched twice
         case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4>(p, st);

@@ -1127,7 +1127,7 @@ bool conv_tile_valid(int tile)
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
     return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
-           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 7) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5);
+           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5);
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
@@ -1136,6 +1136,7 @@ static void tile_dims(int tile, int& bm, int& bn)
     static const int BNs[20] = {128, 64, 128, 64, 32, 128, 64, 128, 64, 32, 128, 64, 128, 64, 128, 128, 128, 64, 128, 64};
     if (tile == CONV_TILE_B3 + 5) { bm = 256; bn = 128; return; }
     if (tile == CONV_TILE_B3R || (tile >= 90 && tile <= 96)) { bm = 128; bn = 128; return; }
+    if (tile == CONV_TILE_B3R + 1) { bm = 128; bn = 64; return; }
     if (tile == CONV_TILE_B3R + 3 || tile == CONV_TILE_B3R + 4) { bm = 128; bn = 256; return; }
     if (tile == CONV_TILE_B3R + 5) { bm = 128; bn = 128; return; }
     if (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5) { static const int g[5] = {0, 1, 2, 3, 10}; tile = g[tile - CONV_TILE_B3]; }

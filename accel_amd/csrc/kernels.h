@@ -54,7 +54,7 @@ struct ConvParams {
     const void* wb3;       // null: Cin % 8 != 0, narrow output, or ACCEL_BF16X3=0
     const float* wws;      // null: not a 64 -> k*256 / 128 -> k*128 1x1 stride-1 layer (or ACCEL_WS1X1=0)
     unsigned wws_bytes;
-    // second-generation bf16x3 kernel (conv_b3r.hip, launch geometries 76, 79, 80, 81): the three bf16 planes once more, in MFMA
+    // second-generation bf16x3 kernel (conv_b3r.hip, launch geometries 76, 77, 79, 80, 81): the three bf16 planes once more, in MFMA
     // fragment order [class][K step][half step][row][16] (weights go global -> VGPR, never through LDS)
     const void* wb3r;      // null where wb3 is null (or ACCEL_B3R=0)
 };
@@ -75,7 +75,7 @@ void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
-#define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
+#define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);
 #define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)
 bool conv_ws_eligible(const ConvParams& p);

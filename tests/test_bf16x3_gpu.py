@@ -47,7 +47,7 @@ def test_conv_bf16x3_every_geometry_within_the_fp32_tolerance(ctx, b3_mode, tile
     assert float(np.abs(got - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))     # the fp32 operator bar of test_ops_gpu
 
 
-@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74, 75, 76, 79, 80, 81])
+@pytest.mark.parametrize("tile", [70, 71, 72, 73, 74, 75, 76, 77, 79, 80, 81])
 def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
     """In fp32 mode the kernel is offered to the autotuner as launch geometries 70-74 of the same convolution."""
     from accel_amd.runtime import AccelError
@@ -64,7 +64,7 @@ def test_bf16x3_geometries_of_an_fp32_layer(ctx, tile):
         ctx.conv2d(rnd(26, 1, 16, 16, 16), rnd(27, 2, 16, 3, 3), None, 1, 1, 1, tile=tile)      # 2 output channels: the strip kernel's layer
 
 
-@pytest.mark.parametrize("tile", [74, 76, 79, 80, 81])
+@pytest.mark.parametrize("tile", [74, 76, 77, 79, 80, 81])
 def test_bf16x3_register_weight_kernel_deconv_splitk_and_batch(ctx, tile):
     """conv_b3r.hip (76, 79, 80, 81: weight fragments global -> VGPR in MFMA order, pixel tile double-buffered in LDS)
     on what the convolution test above does not reach: the four parity classes of the 4x4/2 deconvolution (class-major
