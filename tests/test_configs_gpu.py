@@ -258,6 +258,55 @@ def test_cabi_gather_without_torch_distributed(ctx):
         comm.close()
 
 
+def test_gather_beside_the_next_frames_compute_does_not_disturb_it(demo_cfg, monkeypatch):
+    """The multi-GPU loop runs the RCCL transfer of frame t on the communication stream WHILE frame t+1 computes -- two
+    hardware queues busy at once, the situation in which two-stream plans were seen to go wrong.  On the
+    one GPU of a test box the root's own block is sent through ncclSend / ncclRecv to itself (ACCEL_GATHER_SELF_SENDRECV),
+    frames are submitted back to back without a host wait in between, and every gathered frame must be bit-identical to
+    the frame a run WITHOUT any gather produced: 1024x2048, 12 frames (key + 4 non-key, twice and a bit), logits."""
+    import torch
+    import torch.distributed as dist
+    from accel_amd import demo, dist as adist
+    from accel_amd.core import tester
+    monkeypatch.setenv("ACCEL_GATHER_SELF_SENDRECV", "1")
+    H, W, interval, n = 1024, 2048, 5, 12
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, n)
+    data = demo.build_batches(frames, demo_cfg)
+    try:
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        quiet = []
+        for t in range(n):
+            lg, _ = r.step(t, data[t], interval)
+            quiet.append(lg.asnumpy()[0, :, ::3, ::3].copy())
+        r.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+            m = r.key_predictor._model
+            comm = adist.make_comm(m.ctx)
+            src, nbytes = m.buffer("logits")[0], 19 * H * W * 4
+            recv = [torch.empty((1, 19, H, W), dtype=torch.float32, device="cuda:0") for _ in range(n)]      # one buffer per frame: no host wait in the loop
+            for t in range(n):
+                r.step(t, data[t], interval)
+                comm.gather(src, recv[t].data_ptr(), nbytes, 0)      # staged in compute-stream order, sent while frame t+1 computes
+            comm.sync()
+            got = [x.cpu().numpy()[0, :, ::3, ::3].copy() for x in recv]
+            comm.close()
+            r.close()
+        finally:
+            dist.destroy_process_group()
+        for t in range(n):
+            assert np.array_equal(got[t], quiet[t]), "frame %d gathered beside compute differs from the quiet run by %g" % (
+                t, float(np.abs(got[t] - quiet[t]).max()))
+    finally:
+        tester.release_models()
+
+
 def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     """Accel-50, fp16-MFMA convolutions, 2048x4096 (config 5's frame size), the first three frames of a kf=10 group
     (key, non-key, non-key: the chain through warp + correction branch).  Checked against the fp32 run of the same
