@@ -129,11 +129,10 @@ class Predictor(object):
         H, W, N = int(hw[0]), int(hw[1]), int(N)
         if (N, H, W) in self._plans:
             return self._plans[(N, H, W)]
-        if H % 32 or W % 32:
-            # multiples of 32 keep the two score maps of the fusion (ResNet-101 at stride 16, the correction branch at
-            # stride 32 upsampled 2x) the same size and every 2x2 average pool of FlowNet on whole windows; the reference
-            # itself only ever sees 1024x2048 (and sizes that are not multiples of 16 fail its own shape inference)
-            raise ValueError("image size %dx%d: frame sizes must be multiples of 32" % (H, W))
+        if H % 16 or W % 16:
+            # the task head upsamples H/16 x W/16 scores by exactly 16 (Deconvolution 32x32/16 + Crop(8, 8)): the reference's own
+            # shape inference fails on anything else; it only ever sees 1024x2048
+            raise ValueError("image size %dx%d: frame sizes must be multiples of 16" % (H, W))
         feat_shape = (N, 2048, 1, 1) if self._is_key else (N, 2048, H // 16, W // 16)
         shapes = {"data": (N, 3, H, W), "data_key": (N, 3, H, W), "feat_key": feat_shape}
         shapes = {k: v for k, v in shapes.items() if k in self._symbol.list_arguments()}

@@ -804,6 +804,11 @@ static int finalize_op(accel_plan* p, Op& op)
         }
         if (op.b.set) {
             q.right = op.b.ptr; q.rCs = op.b.Cs;
+            // the right map may be one row / column larger than the left one (stride-32 branch upsampled 2x, frame size a multiple of
+            // 16 only): Deconvolution 32x32/16 + Crop(8, 8) to the frame never reaches its last row / column
+            if (op.b.H < op.a.H || op.b.W < op.a.W || op.b.H > op.a.H + 1 || op.b.W > op.a.W + 1)
+                return fail(ACCEL_ERR_PLAN, "score_tail: right score map %dx%d does not fit the left one %dx%d", op.b.H, op.b.W, op.a.H, op.a.W);
+            if (op.b.H != op.a.H || op.b.W != op.a.W) { q.rHs = op.b.H; q.rWs = op.b.W; }
             if ((rc = upload_param(p, kv_str(kv, "wr"), wn, &q.wr)) ||
                 (rc = upload_param(p, kv_str(kv, "cw"), (size_t)q.ncls * 2 * q.ncls, &q.cw)) ||
                 (rc = upload_param(p, kv_str(kv, "cb"), (size_t)q.ncls, &q.cb))) return rc;
@@ -811,7 +816,7 @@ static int finalize_op(accel_plan* p, Op& op)
             // the bilinear init) -> fuse at score resolution, then upsample ncls maps once
             const HostParam* hl = get_param(p->m, kv_str(kv, "wl"));
             const HostParam* hr = get_param(p->m, kv_str(kv, "wr"));
-            bool uniform = kv_int(kv, "lowres", 1) != 0;
+            bool uniform = kv_int(kv, "lowres", 1) != 0 && !q.rHs;      // fusing at score resolution needs the two maps on one grid
             for (int c = 0; c < q.ncls && uniform; ++c)
                 uniform = !memcmp(hl->data.data(), hl->data.data() + (size_t)c * 1024, 4096) &&
                           !memcmp(hl->data.data(), hr->data.data() + (size_t)c * 1024, 4096);

@@ -134,6 +134,8 @@ struct ScoreTailParams {
     int softmax;                     // apply softmax over classes to the written scores (deeplab test symbol)
     int uniform_w;                   // wl is the same 32x32 filter for every class: 4-pixel-per-thread kernel
     int N;                           // images (blockIdx.z), stacked in every buffer; 0 = 1
+    int rHs, rWs;                    // size of the RIGHT score map when it differs from Hs x Ws (frame sizes that are multiples of 16
+                                     // but not of 32: the stride-32 branch upsampled 2x is one row / column larger); 0 = same
 };
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
 

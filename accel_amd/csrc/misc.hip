@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
     {   // image of the batch
         const size_t zn = blockIdx.z;
         p.left += zn * p.Hs * p.Ws * p.lCs;
-        if (p.right) p.right += zn * p.Hs * p.Ws * p.rCs;
+        if (p.right) p.right += zn * (p.rHs ? p.rHs : p.Hs) * (p.rWs ? p.rWs : p.Ws) * p.rCs;
         p.logits += zn * p.ncls * p.H * p.W;
         p.labels += zn * p.H * p.W;
     }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void score_tail_kernel(ScoreTailParams p)
     upsample_px<NCLS>(p.left, p.lCs, p.wl, p.Hs, p.Ws, Y, X, sl);
     if (p.right) {
         float sr[NCLS];
-        upsample_px<NCLS>(p.right, p.rCs, p.wr, p.Hs, p.Ws, Y, X, sr);
+        upsample_px<NCLS>(p.right, p.rCs, p.wr, p.rHs ? p.rHs : p.Hs, p.rWs ? p.rWs : p.Ws, Y, X, sr);
 #pragma unroll
         for (int k = 0; k < NCLS; ++k) {
             float v = p.cb[k];

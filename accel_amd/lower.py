@@ -673,17 +673,21 @@ class Lowering(object):
         return n.op == "Deconvolution" and n.attrs["kernel"] == (32, 32) and n.attrs["stride"] == (16, 16) \
             and n.attrs["num_group"] == n.attrs["num_filter"] and n.attrs["pad"] == (0, 0) and n.attrs["no_bias"]
 
-    def _tail_branch(self, crop):
+    def _tail_branch(self, crop, first=True):
         if crop.op != "Crop" or crop.attrs["offset"] != (8, 8) or not self._is_upsampler(crop.inputs[0]):
             return None
         up = crop.inputs[0]
         _, n, h, w = self.shape(crop)
-        if (h, w) != (self.H, self.W) or self.shape(up.inputs[0])[2:] != (self.H // 16, self.W // 16):
+        hs, ws = self.shape(up.inputs[0])[2:]
+        # the first (left) map is exactly H/16 x W/16; the second may be one row / column larger: the stride-32 correction
+        # branch upsampled 2x at frame sizes that are multiples of 16 but not of 32 (Crop(8, 8) to the frame drops the excess)
+        ok = (hs, ws) == (self.H // 16, self.W // 16) if first else (self.H // 16 <= hs <= self.H // 16 + 1 and self.W // 16 <= ws <= self.W // 16 + 1)
+        if (h, w) != (self.H, self.W) or self.H % 16 or self.W % 16 or not ok:
             raise NotImplementedError("score upsampling must map H/16 x W/16 scores onto the full image")
         return up
 
     def lower_tail(self, node, crops, corr=None, softmax=None):
-        ups = [self._tail_branch(c) for c in crops]
+        ups = [self._tail_branch(c, first=(i == 0)) for i, c in enumerate(crops)]
         if any(u is None for u in ups):
             raise NotImplementedError("unsupported score tail at %s" % node.name)
         ncls = ups[0].attrs["num_filter"]

@@ -234,13 +234,34 @@ def test_other_aspect_ratios(demo_cfg, H, W):
     _check(outs, G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), 2), "accel-18 %dx%d" % (H, W))
 
 
-def test_size_not_multiple_of_32_is_rejected(demo_cfg):
+@pytest.mark.parametrize("version,H,W", [("18", 144, 272), ("34", 208, 176), ("101", 144, 272), ("18", 1040, 2064)])
+def test_sizes_that_are_multiples_of_16_only(demo_cfg, version, H, W):
+    """The reference binds any size its own shape inference accepts, i.e. any multiple of 16 (the head upsamples H/16 x W/16
+    by exactly 16).  At multiples of 16 that are not multiples of 32 the stride-32 correction branch of Accel-18 / 34,
+    upsampled 2x, is one row / column LARGER than the stride-16 map (9 vs 10 rows at H = 144): Deconvolution 32x32/16 +
+    Crop(8, 8) never reaches the extra row; the fused score tail takes the two maps at their own sizes.  Odd sizes also
+    run through the 'full' / 'valid' pooling conventions and the 2h-1 crops of the FlowNet decoder."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    demo_cfg.SCALES[0] = (min(H, W), max(H, W))
+    arg, aux = synth.model_params(version, H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip(version, demo_cfg, arg, aux, frames, 2)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    _check(outs, G.run_clip(P, version, _oracle_frames(frames, demo_cfg), 2), "accel-%s %dx%d" % (version, H, W))
+
+
+def test_size_not_multiple_of_16_is_rejected(demo_cfg):
     from accel_amd import demo
     from accel_amd.core import tester
     demo_cfg.SCALES[0] = (200, 256)
     arg, aux = synth.model_params("18", 256, 256, demo_cfg)
     try:
-        with pytest.raises(ValueError, match="multiples of 32"):
+        with pytest.raises(ValueError, match="multiples of 16"):
             demo.ClipRunner("18", demo_cfg, arg, aux, (200, 256))
     finally:
         tester.release_models()
