@@ -142,6 +142,25 @@ def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
     check_against_oracle(outs, ref, "config3 accel-101 1024x2048")
 
 
+@pytest.mark.parametrize("version", ["34", "50"])
+def test_accel34_accel50_1024x2048_vs_oracle(demo_cfg, version):
+    """The other two models at the size the reference validates at: a key and a non-key frame against the CPU oracle."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    H, W, interval = 1024, 2048, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params(version, H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip(version, demo_cfg, arg, aux, frames, interval)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, version, _oracle_frames(frames, demo_cfg), interval)
+    check_against_oracle(outs, ref, "accel-%s 1024x2048" % version)
+
+
 def test_config3_accel101_full_size_properties_1024x2048(demo_cfg):
     """Accel-101 at the BASELINE size (the oracle takes minutes there): determinism, fused argmax == argmax of the
     logits, a key frame inside a clip == the same frame first, zero flow + identical frames => warped feature ==
