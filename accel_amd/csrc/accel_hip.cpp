@@ -511,6 +511,21 @@ static int finalize_conv(accel_plan* p, Op& op)
         std::vector<_Float16> ph(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
         if ((rc = dev_upload(p, ph.data(), ph.size() * sizeof(_Float16), &dw_))) return rc;
+        const char* re_ = getenv("ACCEL_B3R");
+        if (!(re_ && re_[0] == '0')) {
+            // the same half-rounded weights once more in MFMA fragment order [class][K step][half step][row][16] for the fp16 form
+            // of conv_b3r.hip (launch geometries 76 / 77 / 79 / 80 / 81 of an f16 layer)
+            const int classes = c.deconv2x ? 4 : 1, steps = c.K_pad / 32;
+            c.w_plane = (size_t)classes * rows * c.K_pad + 2 * (size_t)rows * 32;
+            std::vector<_Float16> pr(c.w_plane, (_Float16)0.f);
+            for (int cl = 0; cl < classes; ++cl)
+                for (int n = 0; n < rows; ++n)
+                    for (int k = 0; k < c.K_pad; ++k)
+                        pr[((((size_t)cl * steps + k / 32) * 2 + ((k >> 4) & 1)) * rows + n) * 16 + (k & 15)] = ph[((size_t)cl * rows + n) * c.K_pad + k];
+            void* d4 = nullptr;
+            if ((rc = dev_upload(p, pr.data(), pr.size() * sizeof(_Float16), &d4))) return rc;
+            c.wb3r = d4;
+        }
     } else if ((rc = dev_upload(p, packed.data(), packed.size() * sizeof(float), &dw_))) return rc;
     c.w = static_cast<const float*>(dw_);
     {
@@ -533,7 +548,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d4))) return rc;
                 c.wb3r = d4;
             }
-        } else if (forced) {
+        } else if (forced && !(c.f16 == 1 && c.wb3r && ft >= CONV_TILE_B3R && ft < CONV_TILE_B3R + 6)) {
             return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with more than "
                                        "4 output channels only", op.name.c_str());
         }
@@ -639,7 +654,18 @@ static int finalize_conv(accel_plan* p, Op& op)
             if ((rc = dev_upload(p, wu.data(), wu.size() * sizeof(float), &du))) return rc;
             c.wu = static_cast<const float*>(du);
             c.wu_bytes = (unsigned)(wu.size() * sizeof(float));
-        } else if (c.force_tile == CONV_TILE_WINO) {
+            const char* be = getenv("ACCEL_BF16X3");
+            const char* wbe = getenv("ACCEL_WINOGRAD_B3");
+            if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0')) || c.force_tile == CONV_TILE_WINO_B3) && !c.f16 && conv_wino_b3_eligible(c)) {
+                // the same transformed weights as three exact bf16 planes in MFMA fragment order: launch geometry 41
+                std::vector<unsigned short> ub;
+                conv_wino_b3_pack(w->data.data(), cout, cin, c.wino_rows, ub);
+                void* db = nullptr;
+                if ((rc = dev_upload(p, ub.data(), ub.size() * sizeof(unsigned short), &db))) return rc;
+                c.wub = db;
+                c.wub_bytes = (unsigned)(ub.size() * sizeof(unsigned short));
+            }
+        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
                                        "size and channels in multiples of 8 only", op.name.c_str());
         }
@@ -956,7 +982,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-5"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-6"
 
 static std::string lib_dir()
 {
@@ -1067,6 +1093,14 @@ static int autotune_plan(accel_plan* p)
                 if (conv_apply(q, CONV_TILE_WINO, 1024, 0) && q.ksplit != ks0) cs.push_back({CONV_TILE_WINO, 1024, 0});
                 if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
             }
+            if (c.wub && !c.f16) {
+                cs.push_back({CONV_TILE_WINO_B3, 0, 0});
+                ConvParams q = c;
+                const size_t base = conv_apply(q, CONV_TILE_WINO_B3, 0, 0);
+                const int ks0 = q.ksplit;
+                if (conv_apply(q, CONV_TILE_WINO_B3, 1024, 0) && q.ksplit != ks0) cs.push_back({CONV_TILE_WINO_B3, 1024, 0});
+                if (base) cs.push_back({CONV_TILE_WINO_B3, 0, 1});
+            }
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
             const int nb3 = c.wb3 ? 5 : 0;
@@ -1075,11 +1109,11 @@ static int autotune_plan(accel_plan* p)
                                         CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
-                if (t >= CONV_TILE_B3 && !nb3) continue;
+                if (t >= CONV_TILE_B3 && t < CONV_TILE_B3R && !nb3) continue;
                 if (t >= CONV_TILE_B3R && !c.wb3r) continue;
                 if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
-                if (c.f16 && !(t <= 3 || t == 10)) continue;
+                if (c.f16 && !(t <= 3 || t == 10 || (c.f16 == 1 && t >= CONV_TILE_B3R && c.wb3r))) continue;
                 cs.push_back({t, 0, 0});
                 ConvParams q = c;
                 const size_t base = conv_apply(q, t, 0, 0);

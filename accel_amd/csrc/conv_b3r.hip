@@ -25,6 +25,7 @@
 #include "conv_epilogue.h"
 
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3_pair_r(float v0, float v1, unsigned& q0, unsigned& q1, unsigned& q2)
 {
@@ -38,7 +39,9 @@ __device__ __forceinline__ void split3_pair_r(float v0, float v1, unsigned& q0, 
 }
 
 // wplane: bf16 elements between the planes; rowsB: rows of a plane (Cout_store rounded up to 128)
-template <int BM, int BN, int WGM, int WGN, bool FAST, int ABL = 0>
+// NPL = 3: bf16x3 (three planes per operand, six products); NPL = 1: the fp16-MFMA mode of plan option dtype=f16 (operands rounded to
+// half -- weights on the host, pixels by the loader --, ONE plane, one v_mfma_f32_32x32x16_f16 product, fp32 accumulate) on the same staging
+template <int BM, int BN, int WGM, int WGN, bool FAST, int ABL = 0, int NPL = 3>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 * 128 ? 4 : 2)) void conv_b3r_kernel(ConvParams p, size_t wplane, int rowsB)
 {
     constexpr int BK = 32, LDK = BK + 8;            // bf16 elements per staged row (80 bytes: conflict-free ds_read_b128)
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     constexpr int AR = BM / RP;
     static_assert(BM % RP == 0, "tile / thread-count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_r[];      // As[2][3][BM][LDK]
-    constexpr int STAGE = 3 * BM * LDK;
+    constexpr int STAGE = NPL * BM * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -130,14 +133,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
         unsigned short* a = smem_r + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            i32x4 q[3];
-            unsigned x0, x1, x2;
-            split3_pair_r(ralo[set][i][0], ralo[set][i][1], x0, x1, x2); q[0][0] = (int)x0; q[1][0] = (int)x1; q[2][0] = (int)x2;
-            split3_pair_r(ralo[set][i][2], ralo[set][i][3], x0, x1, x2); q[0][1] = (int)x0; q[1][1] = (int)x1; q[2][1] = (int)x2;
-            split3_pair_r(rahi[set][i][0], rahi[set][i][1], x0, x1, x2); q[0][2] = (int)x0; q[1][2] = (int)x1; q[2][2] = (int)x2;
-            split3_pair_r(rahi[set][i][2], rahi[set][i][3], x0, x1, x2); q[0][3] = (int)x0; q[1][3] = (int)x1; q[2][3] = (int)x2;
+            if constexpr (NPL == 1) {
+                f16x8r h;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(a + (pl * BM + srow + RP * i) * LDK + scol) = q[pl];
+                for (int e = 0; e < 4; ++e) { h[e] = (_Float16)ralo[set][i][e]; h[4 + e] = (_Float16)rahi[set][i][e]; }
+                *reinterpret_cast<i32x4*>(a + (srow + RP * i) * LDK + scol) = __builtin_bit_cast(i32x4, h);
+            } else {
+                i32x4 q[3];
+                unsigned x0, x1, x2;
+                split3_pair_r(ralo[set][i][0], ralo[set][i][1], x0, x1, x2); q[0][0] = (int)x0; q[1][0] = (int)x1; q[2][0] = (int)x2;
+                split3_pair_r(ralo[set][i][2], ralo[set][i][3], x0, x1, x2); q[0][1] = (int)x0; q[1][1] = (int)x1; q[2][1] = (int)x2;
+                split3_pair_r(rahi[set][i][0], rahi[set][i][1], x0, x1, x2); q[0][2] = (int)x0; q[1][2] = (int)x1; q[2][2] = (int)x2;
+                split3_pair_r(rahi[set][i][2], rahi[set][i][3], x0, x1, x2); q[0][3] = (int)x0; q[1][3] = (int)x1; q[2][3] = (int)x2;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<i32x4*>(a + (pl * BM + srow + RP * i) * LDK + scol) = q[pl];
+            }
         }
     };
 
@@ -145,20 +155,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     // plane layout [K step][half step][row][16 bf16]: lane (frow, half) of N-subtile j reads 16 bytes at
     //   ((2 * ks + kb) * rowsB + n) * 32 + half * 16,   n = n0 + (wn * NI + j) * 32 + frow
     const int frow = lane & 31, half = lane >> 5;
-    const __amdgpu_buffer_rsrc_t wall = make_rsrc(wbase, (unsigned)(4 * wplane) + (unsigned)((size_t)rowsB * p.K_pad * 2) + (unsigned)(rowsB * 128));
+    const __amdgpu_buffer_rsrc_t wall = make_rsrc(wbase, (unsigned)(2 * (NPL - 1) * wplane) + (unsigned)((size_t)rowsB * p.K_pad * 2) + (unsigned)(rowsB * 128));
     unsigned b_voff[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) b_voff[j] = (unsigned)((n0 + (wn * NI + j) * 32 + frow) * 32 + half * 16);
     const unsigned hstep = (unsigned)rowsB * 32u;      // bytes of one half step of one plane
     const unsigned plane_b = (unsigned)(2 * wplane);
-    i32x4 fbr[2][NI][3];      // the two half steps of a K step; each is requested half a step of matrix work before its use
-    if constexpr ((ABL & 2) != 0) for (int b_ = 0; b_ < 2; ++b_) for (int j = 0; j < NI; ++j) for (int pl = 0; pl < 3; ++pl) fbr[b_][j][pl] = i32x4{lane, 1, 2, 3};
+    i32x4 fbr[2][NI][NPL];      // the two half steps of a K step; each is requested half a step of matrix work before its use
+    if constexpr ((ABL & 2) != 0) for (int b_ = 0; b_ < 2; ++b_) for (int j = 0; j < NI; ++j) for (int pl = 0; pl < NPL; ++pl) fbr[b_][j][pl] = i32x4{lane, 1, 2, 3};
     auto load_b = [&](int hs /* global half-step index */, int buf) {
         if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
                 fbr[buf][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(wall, b_voff[j], (unsigned)pl * plane_b + (unsigned)hs * hstep, 0);
     };
 
@@ -171,32 +181,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fk = half * 8;
-    bf16x8r fa[1][MI][3];
+    i32x4 fa[1][MI][NPL];
     auto read_fa = [&](int stage, int kb, int set) {
         const unsigned short* a = smem_r + stage * STAGE + (wm * MI * 32 + frow) * LDK + fk + kb * 16;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[set][i][pl] = *reinterpret_cast<const bf16x8r*>(a + (pl * BM + i * 32) * LDK);
+            for (int i = 0; i < MI; ++i) fa[set][i][pl] = *reinterpret_cast<const i32x4*>(a + (pl * BM + i * 32) * LDK);
     };
     auto mma = [&](int set, int buf) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const bf16x8r b0 = __builtin_bit_cast(bf16x8r, fbr[buf][j][0]), b1 = __builtin_bit_cast(bf16x8r, fbr[buf][j][1]),
-                              b2 = __builtin_bit_cast(bf16x8r, fbr[buf][j][2]);
-                f32x16 c = acc[i][j];      // smallest terms first
-                if constexpr ((ABL & 1) != 0) {      // timing ablation: the operands are consumed, nothing is multiplied
-                    asm volatile("" :: "v"(fa[set][i][0]), "v"(fa[set][i][1]), "v"(fa[set][i][2]), "v"(b0), "v"(b1), "v"(b2));
-                    continue;
+                f32x16 c = acc[i][j];
+                if constexpr (NPL == 1) {
+                    if constexpr ((ABL & 1) != 0) { asm volatile("" :: "v"(fa[set][i][0]), "v"(fbr[buf][j][0])); continue; }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8r, fa[set][i][0]), __builtin_bit_cast(f16x8r, fbr[buf][j][0]), c, 0, 0, 0);
+                } else {
+                    const bf16x8r a0 = __builtin_bit_cast(bf16x8r, fa[set][i][0]), a1 = __builtin_bit_cast(bf16x8r, fa[set][i][1]),
+                                  a2 = __builtin_bit_cast(bf16x8r, fa[set][i][2]);
+                    const bf16x8r b0 = __builtin_bit_cast(bf16x8r, fbr[buf][j][0]), b1 = __builtin_bit_cast(bf16x8r, fbr[buf][j][1]),
+                                  b2 = __builtin_bit_cast(bf16x8r, fbr[buf][j][2]);
+                    if constexpr ((ABL & 1) != 0) {      // timing ablation: the operands are consumed, nothing is multiplied
+                        asm volatile("" :: "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2));
+                        continue;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);      // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][1], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][0], b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][2], b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][0], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][1], b0, c, 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][0], b0, c, 0, 0, 0);
             }
     };
 
@@ -228,35 +245,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 }
 
-template <int BM, int BN, int WGM, int WGN, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int ABL = 0, int NPL = 3>
 static hipError_t launch_b3r(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
-    constexpr size_t lds = (size_t)2 * 3 * BM * 40 * sizeof(unsigned short);
+    constexpr size_t lds = (size_t)2 * NPL * BM * 40 * sizeof(unsigned short);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL, NPL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL, NPL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int rowsB = (int)(p.w_bytes / ((unsigned)p.K_pad * 2u));
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
-    else hipLaunchKernelGGL((conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
+    if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL, NPL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
+    else hipLaunchKernelGGL((conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL, NPL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     return launch_splitk_reduce(p, (int)grid.y, st);
 }
 
-// p.w = the fragment-ordered planes (ConvParams::wb3r), p.w_bytes = bytes of one plane of one class
+// p.w = the fragment-ordered planes (ConvParams::wb3r), p.w_bytes = bytes of one plane of one class; p.f16 == 1: the one-plane fp16 form
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
 {
+    if (p.f16 == 1) {
+        switch (tile) {
+            case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4, 0, 1>(p, st);
+            case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2, 0, 1>(p, st);
+            case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 1>(p, st);
+            case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 1>(p, st);
+            case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 1>(p, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (tile) {
         case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4>(p, st);
         case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2>(p, st);       // 64-channel layers (res2, the ResNet-18 trunk's first stage)

@@ -1126,7 +1126,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
            (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5);
 }
 
@@ -1172,6 +1172,21 @@ size_t conv_plan_split(ConvParams& p)
         if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
         return (size_t)p.ksplit * p.M * p.Cout_store * sizeof(float);
     }
+    if (tile == CONV_TILE_WINO_B3) {
+        // conv_wino_b3.hip: blocks of 64 tiles x 64 channels, K steps of 16 channels; raw partial outputs as for tile 40
+        const long blocks = ((p.M / 4 + 63) / 64) * (long)conv_wino_rows(p.Cout_store) / 64;
+        const int KT = p.Cin / 16, min_steps = 4;
+        const int min_blocks = p.split_target > 0 ? p.split_target : 256;
+        const int target = p.split_target > 0 ? p.split_target : 512;
+        if (blocks >= min_blocks || KT < 2 * min_steps) return 0;
+        int want = (int)((target + blocks - 1) / blocks);
+        int ks = want < KT / min_steps ? want : KT / min_steps;
+        if (ks < 2) return 0;
+        p.kt_per_split = (KT + ks - 1) / ks;
+        p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
+        if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
+        return (size_t)p.ksplit * p.M * p.Cout_store * sizeof(float);
+    }
     tile_dims(tile, bm, bn);
     const long classes = p.deconv2x ? 4 : 1;
     const long blocks = classes * ((p.M + bm - 1) / bm) * ((p.Cout_store + bn - 1) / bn);
@@ -1196,8 +1211,16 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
+    if (p.force_tile == CONV_TILE_WINO_B3) return launch_conv_wino_b3(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
+    if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && p.f16 == 1) {
+        // fp16-MFMA mode on the staging of conv_b3r.hip: one plane of half-rounded weights in MFMA fragment order
+        if (!p.wb3r) return hipErrorInvalidValue;
+        ConvParams q = p;
+        q.w = static_cast<const float*>(p.wb3r);
+        return launch_conv_b3r(q, p.force_tile, st);
+    }
     if (((p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6) || (p.force_tile >= 90 && p.force_tile <= 96)) && !p.f16) {
         if (!p.wb3r) return hipErrorInvalidValue;
         ConvParams q = p;

@@ -2,6 +2,7 @@
 // Activations are fp32 NHWC with a channel stride `Cs` (multiple of 4) that
 // may exceed the logical channel count (concat views, padded channels).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
@@ -57,6 +58,8 @@ struct ConvParams {
     // second-generation bf16x3 kernel (conv_b3r.hip, launch geometries 76, 77, 79, 80, 81): the three bf16 planes once more, in MFMA
     // fragment order [class][K step][half step][row][16] (weights go global -> VGPR, never through LDS)
     const void* wb3r;      // null where wb3 is null (or ACCEL_B3R=0)
+    const void* wub;       // conv_wino_b3.hip: U = G g G^T as three bf16 planes [plane][C/16][16][wino_rows][16]; null: not offered
+    unsigned wub_bytes;
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
@@ -64,10 +67,14 @@ int conv_pick_tile(const ConvParams& p);
 int conv_tile_bk(int tile);
 bool conv_tile_valid(int tile);
 #define CONV_TILE_WINO 40
+#define CONV_TILE_WINO_B3 41      // Winograd F(2x2,3x3) on the bf16 matrix cores, three exact bf16 terms per operand (conv_wino_b3.hip)
 bool conv_wino_eligible(const ConvParams& p);
 int conv_wino_rows(int cout_store);
 void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, float* out);
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
+bool conv_wino_b3_eligible(const ConvParams& p);
+void conv_wino_b3_pack(const float* w, int Cout, int Cin, int rows, std::vector<unsigned short>& out);
+hipError_t launch_conv_wino_b3(const ConvParams& p, hipStream_t st);
 hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st);   // sums ws[split][class][M][Cout_store] + epilogue
 #define CONV_TILE_STEM 50
 bool conv_stem_eligible(const ConvParams& p);

@@ -27,8 +27,9 @@ def h(a):
     return a.astype(np.float16).astype(np.float32)
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 10])
-@pytest.mark.parametrize("C,K,H,W,k,s,p,d", [(64, 136, 23, 31, 3, 2, 2, 2), (256, 72, 9, 13, 1, 1, 0, 1), (128, 200, 20, 36, 3, 1, 1, 1)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 10, 76, 77, 79, 80, 81])
+@pytest.mark.parametrize("C,K,H,W,k,s,p,d", [(64, 136, 23, 31, 3, 2, 2, 2), (256, 72, 9, 13, 1, 1, 0, 1), (128, 200, 20, 36, 3, 1, 1, 1),
+                                            (40, 300, 17, 19, 3, 1, 1, 1)])
 def test_conv_f16_matches_half_rounded_operands(ctx, f16_mode, tile, C, K, H, W, k, s, p, d):
     x, w, b = rnd(1, 1, C, H, W), rnd(2, K, C, k, k, scale=(2.0 / (C * k * k)) ** 0.5), rnd(3, K)
     got = ctx.conv2d(x, w, b, s, p, d, tile=tile)
@@ -38,6 +39,41 @@ def test_conv_f16_matches_half_rounded_operands(ctx, f16_mode, tile, C, K, H, W,
     assert float(np.abs(got - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
     full = O.conv2d(x, w, b, s, p, d)
     assert float(np.abs(got - full).max()) <= 5e-3 * max(1.0, float(np.abs(full).max()))
+
+
+@pytest.mark.parametrize("tile", [0, 76, 77, 79, 80, 81])
+def test_f16_register_weight_kernel_deconv_splitk_and_batch(ctx, f16_mode, tile):
+    """The one-plane fp16 form of conv_b3r.hip (76 / 77 / 79 / 80 / 81 on an f16 layer: half-rounded weights in MFMA fragment
+    order global -> VGPR, pixels rounded by the loader into ONE LDS plane) on the four parity classes of the 4x4/2
+    deconvolution, split-K, a batch of images and an odd number of K steps -- to the same 1e-5 of "rounded operands, fp32
+    sums" as the fp16 kernel of conv_igemm.hip (tile 0, the control)."""
+    from accel_amd import runtime
+    cin, cout, H, W = 96, 160, 9, 13
+    x, w = rnd(40, cin, H, W), rnd(41, cin, cout, 4, 4, scale=0.05)
+    m = runtime.Model(ctx)
+    try:
+        m.set_param("w_weight", w)
+        al = lambda b: (b + 255) // 256 * 256
+        o_y = al(H * W * cin * 4)
+        t = "option graph=0\narena bytes=%d\npbuf name=x bytes=%d\npbuf name=y bytes=%d\n" % (o_y + al(4 * H * W * cout * 4), cin * H * W * 4, cout * 4 * H * W * 4)
+        t += "import_nchw src=x:0:%d:%d:%d:%d dst=A:0:%d:%d:%d:%d\n" % (cin, cin, H, W, cin, cin, H, W)
+        t += "conv name=c in=A:0:%d:%d:%d:%d out=A:%d:%d:%d:%d:%d w=w_weight act=0 cin=%d cout=%d mode=deconv2x tile=%d\n" % (
+            cin, cin, H, W, o_y, cout, cout, 2 * H, 2 * W, cin, cout, tile)
+        t += "export_nchw src=A:%d:%d:%d:%d:%d dst=y:0:%d:%d:%d:%d\n" % (o_y, cout, cout, 2 * H, 2 * W, cout, cout, 2 * H, 2 * W)
+        plan = m.add_plan("p", t)
+        m.write("x", x)
+        plan.finalize()
+        plan.run()
+        got = m.read("y", (1, cout, 2 * H, 2 * W))
+    finally:
+        m.close()
+    ref = O.deconv2d(h(x[None]), h(w), None, 2, 1)
+    assert float(np.abs(got - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    for (N, C, K, Hh, Ww, k, s_, p_, d_) in ((1, 512, 136, 8, 16, 3, 1, 1, 1), (3, 64, 72, 20, 28, 3, 1, 2, 2), (2, 96, 64, 12, 10, 5, 2, 2, 1)):
+        xx, ww, bb = rnd(42, N, C, Hh, Ww), rnd(43, K, C, k, k, scale=(2.0 / (C * k * k)) ** 0.5), rnd(44, K)
+        ref = O.conv2d(h(xx), h(ww), bb, s_, p_, d_)
+        got = ctx.conv2d(xx, ww, bb, s_, p_, d_, tile=tile)
+        assert float(np.abs(got - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max())), (N, C, K)
 
 
 def test_deconv_and_dcn_f16(ctx, f16_mode):

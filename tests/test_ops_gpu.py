@@ -294,30 +294,42 @@ WINO_CASES = [
 ]
 
 
+# 41 = the same position-GEMMs on the bf16 matrix cores with three exact bf16 terms per operand (conv_wino_b3.hip)
+@pytest.mark.parametrize("wt", [40, 41])
 @pytest.mark.parametrize("N,C,K,H,W", WINO_CASES)
-def test_conv2d_winograd_matches_oracle(ctx, N, C, K, H, W):
+def test_conv2d_winograd_matches_oracle(ctx, N, C, K, H, W, wt):
     x, w, b = rnd(50, N, C, H, W), rnd(51, K, C, 3, 3, scale=(2.0 / (C * 9)) ** 0.5), rnd(52, K)
     ref = O.conv2d(x, w, b, 1, 1, 1)
-    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=40), ref)
+    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=wt), ref)
     # and against the direct kernel on the same inputs: two evaluations of one function on this GPU
     direct = ctx.conv2d(x, w, b, 1, 1, 1, tile=3)
-    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=40), direct, 2e-5)
+    close(ctx.conv2d(x, w, b, 1, 1, 1, tile=wt), direct, 2e-5)
 
 
-def test_conv2d_winograd_fused_epilogue_and_borders(ctx):
+def test_conv2d_winograd_b3_equals_the_fp32_winograd_kernel_to_rounding(ctx):
+    """Geometry 41 evaluates the SAME expression as geometry 40 (fp32 B^T d B, fp32 U, fp32 sums) with the products formed
+    from three-term splits: the two must agree to fp32 rounding of the sums, far inside the op tolerance."""
+    for (N, C, K, H, W) in ((1, 256, 256, 16, 32), (2, 64, 64, 32, 32), (1, 512, 128, 8, 16)):
+        x, w, b = rnd(53, N, C, H, W, scale=3.0), rnd(54, K, C, 3, 3, scale=(2.0 / (C * 9)) ** 0.5), rnd(55, K)
+        a, bb = ctx.conv2d(x, w, b, 1, 1, 1, tile=40), ctx.conv2d(x, w, b, 1, 1, 1, tile=41)
+        assert float(np.abs(a - bb).max()) <= 4e-6 * max(1.0, float(np.abs(a).max())), (N, C, K)
+
+
+@pytest.mark.parametrize("wt", [40, 41])
+def test_conv2d_winograd_fused_epilogue_and_borders(ctx, wt):
     C, K, H, W = 64, 96, 20, 28
     x, w = rnd(60, 1, C, H, W), rnd(61, K, C, 3, 3, scale=0.05)
     scale, shift, res = rnd(62, K), rnd(63, K), rnd(64, 1, K, H, W)
     ref = O.conv2d(x, w, None, 1, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None] + res
-    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=1, tile=40), O.relu(ref))
-    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=2, slope=0.1, tile=40),
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=1, tile=wt), O.relu(ref))
+    close(ctx.conv2d(x, w, None, 1, 1, 1, scale=scale, shift=shift, residual=res, act=2, slope=0.1, tile=wt),
           O.leaky_relu(ref, 0.1))
     # an impulse in every corner and on every edge: the zero padding of the 4x4 input patches
     xi = np.zeros((1, 16, 6, 8), np.float32)
     for (yy, xx) in ((0, 0), (0, 7), (5, 0), (5, 7), (0, 3), (5, 4), (2, 0), (3, 7)):
         xi[0, :, yy, xx] = rnd(65 + yy + xx, 16)
     wi = rnd(66, 32, 16, 3, 3)
-    np.testing.assert_allclose(ctx.conv2d(xi, wi, None, 1, 1, 1, tile=40), O.conv2d(xi, wi, None, 1, 1, 1), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ctx.conv2d(xi, wi, None, 1, 1, 1, tile=wt), O.conv2d(xi, wi, None, 1, 1, 1), rtol=0, atol=2e-5)
 
 
 def test_conv2d_winograd_rejects_other_geometries(ctx):
@@ -328,6 +340,10 @@ def test_conv2d_winograd_rejects_other_geometries(ctx):
             ctx.conv2d(x, w, None, s, p, d, tile=40)
     with pytest.raises(AccelError, match="Winograd"):
         ctx.conv2d(rnd(72, 1, 64, 7, 9), w, None, 1, 1, 1, tile=40)       # odd output size
+    with pytest.raises(AccelError, match="Winograd"):
+        ctx.conv2d(x, w, None, 2, 1, 1, tile=41)
+    with pytest.raises(AccelError, match="Winograd"):
+        ctx.conv2d(rnd(73, 1, 24, 8, 8), rnd(74, 64, 24, 3, 3), None, 1, 1, 1, tile=41)     # 41 needs channels in multiples of 16
     with pytest.raises(AccelError, match="not part of this build"):
         ctx.conv2d(x, w, None, 1, 1, 1, tile=21)                          # timing-only ablation id: diagnostics build only
 
