@@ -656,7 +656,20 @@ static int finalize_conv(accel_plan* p, Op& op)
             c.wu_bytes = (unsigned)(wu.size() * sizeof(float));
             const char* be = getenv("ACCEL_BF16X3");
             const char* wbe = getenv("ACCEL_WINOGRAD_B3");
-            if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0')) || c.force_tile == CONV_TILE_WINO_B3) && !c.f16 && conv_wino_b3_eligible(c)) {
+            // accuracy budget: Winograd evaluations carry about 3x the rounding error of a direct one, and the plan decides which
+            // layers may take the bf16 form (conv key wb3=0 withholds it; ACCEL_WB3_SKIP = comma-separated name fragments, diagnostics)
+            bool wb3_ok = kv_int(kv, "wb3", 1) != 0;
+            if (const char* sk = getenv("ACCEL_WB3_SKIP")) {
+                std::string all(sk); size_t a0_ = 0;
+                while (a0_ <= all.size()) {
+                    size_t e_ = all.find(',', a0_); if (e_ == std::string::npos) e_ = all.size();
+                    const std::string frag = all.substr(a0_, e_ - a0_);
+                    if (!frag.empty() && op.name.find(frag) != std::string::npos) wb3_ok = false;
+                    a0_ = e_ + 1;
+                }
+            }
+            const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U;
+            if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0') && wb3_ok) || wb3_forced) && !c.f16 && conv_wino_b3_eligible(c)) {
                 // the same transformed weights as three exact bf16 planes in MFMA fragment order: launch geometry 41
                 std::vector<unsigned short> ub;
                 conv_wino_b3_pack(w->data.data(), cout, cin, c.wino_rows, ub);
@@ -665,7 +678,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 c.wub = db;
                 c.wub_bytes = (unsigned)(ub.size() * sizeof(unsigned short));
             }
-        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3) {
+        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
                                        "size and channels in multiples of 8 only", op.name.c_str());
         }
@@ -982,7 +995,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-6"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-7"
 
 static std::string lib_dir()
 {
@@ -1094,12 +1107,14 @@ static int autotune_plan(accel_plan* p)
                 if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
             }
             if (c.wub && !c.f16) {
-                cs.push_back({CONV_TILE_WINO_B3, 0, 0});
-                ConvParams q = c;
-                const size_t base = conv_apply(q, CONV_TILE_WINO_B3, 0, 0);
-                const int ks0 = q.ksplit;
-                if (conv_apply(q, CONV_TILE_WINO_B3, 1024, 0) && q.ksplit != ks0) cs.push_back({CONV_TILE_WINO_B3, 1024, 0});
-                if (base) cs.push_back({CONV_TILE_WINO_B3, 0, 1});
+                for (int wt : {CONV_TILE_WINO_B3, CONV_TILE_WINO_B3U}) {
+                    cs.push_back({wt, 0, 0});
+                    ConvParams q = c;
+                    const size_t base = conv_apply(q, wt, 0, 0);
+                    const int ks0 = q.ksplit;
+                    if (conv_apply(q, wt, 1024, 0) && q.ksplit != ks0) cs.push_back({wt, 1024, 0});
+                    if (base) cs.push_back({wt, 0, 1});
+                }
             }
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
@@ -1121,6 +1136,10 @@ static int autotune_plan(accel_plan* p)
                 if (conv_apply(q, t, 1024, 0) && q.ksplit != ks0) cs.push_back({t, 1024, 0});
                 if (base) cs.push_back({t, 0, 1});
             }
+        }
+        if (const char* fw = getenv("ACCEL_WB3_FORCE"); fw && c.wub && !c.f16) {      // diagnostics: every layer that can take 41 / 42, does
+            cs.clear();
+            cs.push_back({atoi(fw), 0, 0});
         }
         for (const Cand& k : cs) { ConvParams q = c; size_t w = conv_apply(q, k.tile, k.split_target, k.no_split); if (w > ws_need) ws_need = w; }
     }
@@ -1160,7 +1179,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it == g_tune_cache.end()) {

@@ -39,6 +39,7 @@ constexpr int KK = 64;                 // output channels per block
 constexpr int BKC = 16;                // input channels per K step
 constexpr int VPS = TT * BKC + 8;      // floats per position of the V image (+32 B: the four patch columns of a quad hit different banks)
 constexpr int VSTAGE = 16 * VPS;
+constexpr size_t WB_LDS_U = (size_t)2 * VSTAGE * sizeof(float) + 6 * 66 * 64 + 1024;      // geometry 42: two V stages + the raw copy (at most 6 x 66 pixels x 64 B) + a dump row
 constexpr size_t WB_LDS = (size_t)2 * VSTAGE * sizeof(float) + 512 * 16;      // two V stages (132096 B; the exchange image [16][64][32] fp32 = 131072 B fits) + the patch offsets
 
 __device__ __forceinline__ float quad_2211w(float v)
@@ -58,9 +59,11 @@ __device__ __forceinline__ void split3_pair_w(float v0, float v1, int& q0, int& 
 }
 }  // namespace
 
-// VAR: bit 0 = channel-block-major block order; diagnostics (timing only, wrong results): 2 = no MFMAs, 4 = no weight loads,
-// 8 = no patch loads / transform, 16 = no split
-template <int VAR>
+// VAR = 0 is the product; the other values are timing ablations of the diagnostics build (bits listed at the launcher)
+// UL (launch geometry 42): the block is a BH x BW rectangle of tiles (8x8, 4x16 or 2x32) and the UNION of its 64 patches --
+// (2 BH + 2) x (2 BW + 2) pixels, 20-25 KB per K step instead of 64 KB -- is loaded once, 64 contiguous bytes per 4 lanes, into
+// an LDS copy from which the threads take their patch columns (one more barrier per K step).
+template <int VAR, bool UL = false>
 __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -77,6 +80,17 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 
     const int TH = p.Ho >> 1, TW = p.Wo >> 1, THW = TH * TW;
     const int T = p.wino_T;
+    // UL: block rectangle (p.wino_bhs = log2 BH), its origin (image un, tile row uty0, tile column utx0)
+    const int bhs = UL ? p.wino_bhs : 0, bws = 6 - bhs, BWm = (1 << bws) - 1;
+    const int RW = (2 << bws) + 2, RH = (2 << bhs) + 2;
+    int un = 0, uty0 = 0, utx0 = 0;
+    if constexpr (UL) {
+        const int BX = (TW + BWm) >> bws, BY = (TH + (1 << bhs) - 1) >> bhs;
+        un = mt / (BX * BY);
+        const int rem = mt - un * (BX * BY);
+        const int by = rem / BX;
+        uty0 = by << bhs; utx0 = (rem - by * BX) << bws;
+    }
     const int nk_all = p.Cin / BKC;
     const int kb = p.ksplit > 1 ? (int)blockIdx.y * p.kt_per_split : 0;
     const int nk = p.ksplit > 1 ? min(p.kt_per_split, nk_all - kb) : nk_all;
@@ -88,23 +102,57 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     // the four row offsets of this thread's patch column are needed once per step only: they live in the spare LDS behind the
     // two V stages (one ds_read_b128 per step) instead of in four registers
     unsigned* aoff_lds = reinterpret_cast<unsigned*>(smem + 2 * VSTAGE) + tid * 4;
-    {
+    if constexpr (!UL) {
         unsigned a_off[4];
         const int tg = m0 + tl;
         const bool ok = tg < T;
-        const int tt = ok ? tg : 0;
+        const int tt = ok ? ((VAR & 1024) ? (tg & ~7) : tg) : 0;      // diagnostics 1024: the 8 tiles of a load instruction fetch the same patch
         const int n = tt / THW, rem = tt - n * THW;
         const int ty = rem / TW, tx = rem - ty * TW;
-        const int ix = 2 * tx - 1 + j;
+        // diagnostics 2048 (wrong results): the same bytes with 4 adjacent lanes on 64 contiguous bytes of one pixel
+        const int ix = (VAR & 2048) ? 2 * tx - 1 + ((tid >> 2) & 1) : 2 * tx - 1 + j;
+        const int qd = (VAR & 2048) ? (tid & 3) : q;
         const bool okx = ok && (unsigned)ix < (unsigned)p.W;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int iy = 2 * ty - 1 + r;
             a_off[r] = (okx && (unsigned)iy < (unsigned)p.H)
-                           ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.xCs + 4 * q) * 4) : OOB;
+                           ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.xCs + 4 * qd) * 4) : OOB;
         }
         *reinterpret_cast<i32x4*>(aoff_lds) = i32x4{(int)a_off[0], (int)a_off[1], (int)a_off[2], (int)a_off[3]};
     }
+    // UL: the raw copy [RH x RW pixels][16 channels] fp32 behind the two V stages; chunk c of pixel (y, x) at slot c ^ (((x >> 1) & 1) << 1)
+    // (the patch-column reads of 4 adjacent pixels x 2 chunks then hit 8 different bank groups).  Slot s = tid + 512 i of the
+    // loader = (pixel s >> 2, chunk s & 3): 4 adjacent lanes fetch the 64 contiguous bytes of one pixel.
+    float* rawS = smem + 2 * VSTAGE;
+    unsigned g_off[4];
+    int g_dst[4];
+    f32x4 g[4];
+    int rr_off = 0;
+    if constexpr (UL) {
+        const float inv_rw = 1.0f / (float)RW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sl = tid + 512 * i, px = sl >> 2, c = sl & 3;
+            int py, pxx;
+            divmod_small(px, RW, inv_rw, py, pxx);
+            const int iy = 2 * uty0 - 1 + py, ix = 2 * utx0 - 1 + pxx;
+            const bool ok = px < RH * RW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            g_off[i] = ok ? (unsigned)((((un * p.H + iy) * p.W + ix) * p.xCs + 4 * c) * 4) : OOB;
+            g_dst[i] = px < RH * RW ? px * 16 + ((c ^ (((pxx >> 1) & 1) << 1)) << 2) : RH * RW * 16 + lane * 4;      // slots past the rectangle: a dump row
+        }
+        const int tyl = tl >> bws, txl = tl & BWm, pxx = 2 * txl + j;
+        rr_off = ((2 * tyl) * RW + pxx) * 16 + ((q ^ (((pxx >> 1) & 1) << 1)) << 2);      // row r: + r * RW * 16; quad q + 2: ^ 8
+    }
+    auto load_g = [&](int k) {
+        const unsigned ko = (unsigned)(kb + min(k, nk - 1)) * (BKC * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = buf_load4(xr, g_off[i] != OOB ? g_off[i] + ko : OOB);
+    };
+    auto store_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(rawS + g_dst[i]) = g[i];
+    };
     // V image: [position][tile][16 channels] fp32, the 16-byte chunk c of a tile row at physical slot c ^ ((tile >> 1) & 3):
     // the fragment reads (32 consecutive tiles, one chunk each) and these stores are then bank-conflict free
     const int lsw = (tl >> 1) & 3;
@@ -115,7 +163,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     if constexpr ((VAR & 32) != 0) for (int it = 0; it < 2; ++it) for (int r = 0; r < 4; ++r) d[it][r] = f32x4{1.f, 2.f, (float)lane, 3.f};
     auto load_d = [&](int k, int it) {
         if constexpr ((VAR & 8) != 0 || (VAR & 32) != 0) return;
-        const unsigned ko = (unsigned)(kb + min(k, nk - 1)) * (BKC * 4) + (unsigned)it * 32u;
+        const unsigned ko = (unsigned)(kb + min(k, nk - 1)) * (BKC * 4) + (unsigned)it * ((VAR & 2048) ? (unsigned)(2 * p.xCs * 4) : 32u);
         const i32x4 ao = *reinterpret_cast<const i32x4*>(aoff_lds);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -125,6 +173,10 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         if constexpr ((VAR & 8) != 0) return;
         if constexpr ((VAR & 64) != 0) { asm volatile("" :: "v"(d[it][0]), "v"(d[it][1]), "v"(d[it][2]), "v"(d[it][3])); return; }
         float* vs = smem + stage * VSTAGE + (it ? v_dst0 + (((q ^ lsw) & 2) ? -8 : 8) : v_dst0);      // quad q + 2: slot (q ^ lsw) ^ 2
+        if constexpr (UL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[it][r] = *reinterpret_cast<const f32x4*>(rawS + ((rr_off + r * RW * 16) ^ (it ? 8 : 0)));
+        }
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             f32x4 vo;
@@ -155,7 +207,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         if constexpr ((VAR & 4) != 0) return;
         const unsigned so = (unsigned)(kb + min(k, nk - 1)) * u_step + (unsigned)pos * u_pos + (unsigned)jj * 1024u;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, (VAR & 128) ? 2 : (VAR & 512) ? 17 : 0);
+        for (int pl = 0; pl < 3; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, (VAR & 128) ? 2 : 0);
     };
     f32x4 raw[2][2];        // fp32 fragment of one position: [mi][channel half]
     auto read_raw = [&](int stage, int pos, int mi) {
@@ -205,14 +257,31 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     i32x4 a0[2][3], a1[2][3];
 
     // ---- prologue: stage 0 = step 0 ----
+    if constexpr (UL) {
+        load_g(0);
+        load_b(0, 0, P0, 0); load_b(1, 0, P0, 1); load_b(2, 0, P1, 0); load_b(3, 0, P1, 1);
+        store_g();
+        load_g(1);
+        lds_barrier();                       // raw copy = patches of step 0
+        transform(0, 0, 0, 4);
+        transform(0, 1, 0, 4);
+        lds_barrier();                       // V stage 0 complete, raw copy read by everybody
+        store_g();
+        load_g(2);
+        lds_barrier();                       // raw copy = patches of step 1
+        read_raw(0, P0, 0);
+        split_raw(a0, 0);
+    } else {
     load_d(0, 0); load_d(0, 1);
-    load_b(0, 0, P0, 0); load_b(1, 0, P0, 1); load_b(2, 0, P1, 0); load_b(3, 0, P1, 1);
-    transform(0, 0, 0, 4);
-    transform(0, 1, 0, 4);
-    load_d(1, 0); load_d(1, 1);
-    lds_barrier();
-    read_raw(0, P0, 0);
-    split_raw(a0, 0);
+        load_b(0, 0, P0, 0); load_b(1, 0, P0, 1); load_b(2, 0, P1, 0); load_b(3, 0, P1, 1);
+        transform(0, 0, 0, 4);
+        transform(0, 1, 0, 4);
+        load_d(1, 0); load_d(1, 1);
+        lds_barrier();
+        read_raw(0, P0, 0);
+        split_raw(a0, 0);
+
+    }
 
     // One K step = four phases of 12 MFMAs (one position x one 32-channel group each).  What prepares the next fragments and
     // the next step is spread over the phases, and the scheduling groups at the end of each phase interleave it with the
@@ -226,6 +295,54 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
             __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                                       \
         }                                                                                             \
     } while (0)
+    if constexpr (UL) {
+        // raw copy = patches of step k+1, g = patches of step k+2 (in flight); barriers: V (end of phase 1), raw (end of phase 3)
+        for (int k = 0; k < nk; ++k) {
+            const int cur = k & 1;
+            // phase 0: P0, channels 0-31 | P0's second tile half, patch item 0 of step k+1: raw copy -> transform -> V stage cur^1
+            read_raw(cur, P0, 1);
+            mma(0, 0, 0, a0, 0);
+            split_raw(a0, 1);
+            mma(0, 0, 0, a0, 1);
+            transform(cur ^ 1, 0, 0, 4);
+            WB_INTERLEAVE(8);
+            WB_FENCE();
+            load_b(0, k + 1, P0, 0);
+            WB_FENCE();
+            // phase 1: P0, channels 32-63 | P1's first tile half, patch item 1
+            read_raw(cur, P1, 0);
+            mma(0, 1, 1, a0, 0);
+            split_raw(a1, 0);
+            mma(0, 1, 1, a0, 1);
+            transform(cur ^ 1, 1, 0, 4);
+            WB_INTERLEAVE(8);
+            WB_FENCE();
+            load_b(1, k + 1, P0, 1);
+            lds_barrier();                  // V stage cur^1 complete; the raw copy has been read by everybody
+            WB_FENCE();
+            // phase 2: P1, channels 0-31 | P1's second tile half
+            read_raw(cur, P1, 1);
+            mma(1, 0, 2, a1, 0);
+            split_raw(a1, 1);
+            mma(1, 0, 2, a1, 1);
+            WB_INTERLEAVE(4);
+            WB_FENCE();
+            load_b(2, k + 1, P1, 0);
+            WB_FENCE();
+            // phase 3: P1, channels 32-63 | P0's first tile half of step k+1; the patches of step k+2 go to the raw copy
+            read_raw(cur ^ 1, P0, 0);
+            mma(1, 1, 3, a1, 0);
+            split_raw(a0, 0);
+            mma(1, 1, 3, a1, 1);
+            store_g();
+            WB_INTERLEAVE(4);
+            WB_FENCE();
+            load_b(3, k + 1, P1, 1);
+            load_g(k + 3);
+            lds_barrier();                  // raw copy = patches of step k+2; V stage cur is free
+            WB_FENCE();
+        }
+    } else
     for (int k = 0; k < nk; ++k) {
         const int cur = k & 1;
         // phase 0: P0, channels 0-31 | split of P0's second tile half, transform of patch item 0 of step k+1
@@ -276,12 +393,19 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 
     // ---- exchange + output transform + epilogue ----
     const int et = tid >> 3, ecq = tid & 7;                 // this thread finishes tile et, channels 4*ecq .. +3 of each round
-    const int tg = m0 + et;
-    int en, erem, ety, etx;
-    {
+    int tg, en, ety, etx;
+    bool tile_ok;
+    if constexpr (UL) {
+        en = un; ety = uty0 + (et >> bws); etx = utx0 + (et & BWm);
+        tile_ok = ety < TH && etx < TW;
+        tg = 0;
+    } else {
+        tg = m0 + et;
+        int erem;
         const float inv_thw = 1.0f / (float)THW, inv_tw = 1.0f / (float)TW;
         divmod_small(tg < T ? tg : 0, THW, inv_thw, en, erem);
         divmod_small(erem, TW, inv_tw, ety, etx);
+        tile_ok = tg < T;
     }
     const unsigned pix00 = (unsigned)((en * p.Ho + 2 * ety) * p.Wo + 2 * etx);
     const unsigned pix[4] = {pix00, pix00 + 1, pix00 + (unsigned)p.Wo, pix00 + (unsigned)p.Wo + 1};
@@ -296,7 +420,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int co = n0 + jj * 32 + 4 * ecq;
-        const bool ok = co < p.Cout_store && tg < T;
+        const bool ok = co < p.Cout_store && tile_ok;
         f32x4 rv[4];
         if (p.res && p.ksplit <= 1) {
 #pragma unroll
@@ -399,38 +523,64 @@ void conv_wino_b3_pack(const float* w, int Cout, int Cin, int rows, std::vector<
         }
 }
 
-hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st)
+// geometry 42: tile-block shape for an output of TH x TW tiles, and the number of blocks
+long conv_wino_b3u_blocks(const ConvParams& p, int* bhs)
+{
+    const int TH = p.Ho / 2, TW = p.Wo / 2;
+    const int s = TH >= 8 ? 3 : TH >= 4 ? 2 : 1;
+    if (bhs) *bhs = s;
+    const int BH = 1 << s, BW = 64 >> s;
+    const long n = p.M / ((long)p.Ho * p.Wo);
+    return n * ((TH + BH - 1) / BH) * ((TW + BW - 1) / BW);
+}
+
+hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_loader)
 {
     ConvParams p = p0;
     if (!conv_wino_b3_eligible(p) || !p.wub) return hipErrorInvalidValue;
     p.wino_T = p.M / 4;
     p.MT = (p.wino_T + TT - 1) / TT;
+    if (union_loader) p.MT = (int)conv_wino_b3u_blocks(p, &p.wino_bhs);
     p.NT = p.wino_rows / KK;
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("ACCEL_WB3_VARIANT"); var = e ? atoi(e) : 0; }
+    const size_t lds = union_loader ? WB_LDS_U : WB_LDS;
     auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WB_LDS);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(512), WB_LDS, st, p);
+        static std::vector<const void*> attr_done;      // one hipFuncSetAttribute per kernel and process
+        const void* kp = reinterpret_cast<const void*>(kern);
+        bool done = false;
+        for (const void* d_ : attr_done) done |= d_ == kp;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done.push_back(kp);
+        }
+        hipLaunchKernelGGL(kern, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(512), lds, st, p);
         return hipSuccess;
     };
     hipError_t le;
-    switch (var) {
-        case 1: le = go(&conv_wino_b3_kernel<1>); break;
+    if (union_loader) le = go(&conv_wino_b3_kernel<0, true>);
+    else {
 #ifdef ACCEL_CONV_DIAG
-        case 3: le = go(&conv_wino_b3_kernel<3>); break;
-        case 5: le = go(&conv_wino_b3_kernel<5>); break;
-        case 9: le = go(&conv_wino_b3_kernel<9>); break;
-        case 17: le = go(&conv_wino_b3_kernel<17>); break;
-        case 31: le = go(&conv_wino_b3_kernel<31>); break;
-        case 128: le = go(&conv_wino_b3_kernel<128>); break;      // weight loads non-temporal
-        case 256: le = go(&conv_wino_b3_kernel<256>); break;      // patch loads non-temporal
-        case 384: le = go(&conv_wino_b3_kernel<384>); break;
-        case 512: le = go(&conv_wino_b3_kernel<512>); break;      // weight loads sc0 sc1
-        case 33: le = go(&conv_wino_b3_kernel<33>); break;      // transform + LDS stores of constant patches (no patch loads)
-        case 65: le = go(&conv_wino_b3_kernel<65>); break;      // patch loads only (no transform, no LDS stores)
-#endif
+    // timing-only ablations (WRONG results by design; diagnostics build only): ACCEL_WB3_VARIANT = sum of the VAR bits
+    static int var = -1;
+    if (var < 0) { const char* e = getenv("ACCEL_WB3_VARIANT"); var = e ? atoi(e) : 0; }
+    switch (var) {
+        case 1: le = go(&conv_wino_b3_kernel<1>); break;        // channel-block-major block order (correct results)
+        case 3: le = go(&conv_wino_b3_kernel<3>); break;        // no MFMAs
+        case 5: le = go(&conv_wino_b3_kernel<5>); break;        // no weight loads
+        case 9: le = go(&conv_wino_b3_kernel<9>); break;        // no patch loads, no transform, no V stores
+        case 17: le = go(&conv_wino_b3_kernel<17>); break;      // no split
+        case 31: le = go(&conv_wino_b3_kernel<31>); break;      // barriers + fragment reads + epilogue only
+        case 33: le = go(&conv_wino_b3_kernel<33>); break;      // transform + V stores of constant patches (no patch loads)
+        case 65: le = go(&conv_wino_b3_kernel<65>); break;      // patch loads only (no transform, no V stores)
+        case 128: le = go(&conv_wino_b3_kernel<128>); break;    // weight loads non-temporal
+        case 256: le = go(&conv_wino_b3_kernel<256>); break;    // patch loads non-temporal
+        case 1024: le = go(&conv_wino_b3_kernel<1024>); break;  // the 8 tiles of a load instruction fetch the same patch
+        case 2048: le = go(&conv_wino_b3_kernel<2048>); break;  // 4 adjacent lanes on 64 contiguous bytes
         default: le = go(&conv_wino_b3_kernel<0>); break;
+    }
+#else
+    le = go(&conv_wino_b3_kernel<0>);
+#endif
     }
     if (le != hipSuccess) return le;
     if (p.ksplit > 1) {

@@ -48,6 +48,7 @@ struct ConvParams {
     unsigned wu_bytes;
     int wino_rows;         // output-channel rows of wu (Cout_store rounded up to the block's 64)
     int wino_T;            // 2x2 output tiles = M / 4, filled by the launcher
+    int wino_bhs;          // geometry 42: log2 of the tile-block height (3 / 2 / 1 = 8x8 / 4x16 / 2x32 tiles), filled by the launcher
     // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
     const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
     // weight-stationary streaming 1x1 variant (conv_1x1ws.hip, tile id 60): weights as the LDS image per column group
@@ -67,6 +68,7 @@ int conv_pick_tile(const ConvParams& p);
 int conv_tile_bk(int tile);
 bool conv_tile_valid(int tile);
 #define CONV_TILE_WINO 40
+#define CONV_TILE_WINO_B3U 42     // the same with the union of the block's patches loaded once into an LDS copy (tile blocks 8x8 / 4x16 / 2x32)
 #define CONV_TILE_WINO_B3 41      // Winograd F(2x2,3x3) on the bf16 matrix cores, three exact bf16 terms per operand (conv_wino_b3.hip)
 bool conv_wino_eligible(const ConvParams& p);
 int conv_wino_rows(int cout_store);
@@ -74,7 +76,8 @@ void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, fl
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
 bool conv_wino_b3_eligible(const ConvParams& p);
 void conv_wino_b3_pack(const float* w, int Cout, int Cin, int rows, std::vector<unsigned short>& out);
-hipError_t launch_conv_wino_b3(const ConvParams& p, hipStream_t st);
+hipError_t launch_conv_wino_b3(const ConvParams& p, hipStream_t st, bool union_loader = false);
+long conv_wino_b3u_blocks(const ConvParams& p, int* bhs);
 hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st);   // sums ws[split][class][M][Cout_store] + epilogue
 #define CONV_TILE_STEM 50
 bool conv_stem_eligible(const ConvParams& p);
