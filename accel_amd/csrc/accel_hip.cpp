@@ -995,7 +995,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-7"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-8"
 
 static std::string lib_dir()
 {
@@ -1182,6 +1182,13 @@ static int autotune_plan(accel_plan* p)
                       c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
+        if (it != g_tune_cache.end()) {
+            // a table entry is only replayed if it names one of THIS layer's candidates (a table written by another build, or a
+            // geometry the plan withholds from the layer, must not turn into an invalid launch): otherwise the layer is timed again
+            bool known = false;
+            for (const auto& k : cands[i]) known |= k.tile == it->second.tile;
+            if (!known) { g_tune_cache.erase(it); it = g_tune_cache.end(); }
+        }
         if (it == g_tune_cache.end()) {
             // Each candidate is timed the way the launch will run inside the plan: weights cold (L2 and the 256 MB
             // Infinity Cache scrubbed by a memset of a larger scratch buffer), input freshly produced by the

@@ -107,6 +107,24 @@ class Lowering(object):
         self.derived_bufs = {} # derived persistent buffer -> {"from", "w", "cin", "cout", "H", "W"} (see lower_warp)
         self.shapes = infer_shapes(sym, input_shapes)
         self.nodes = sym.topo()
+        # Accuracy budget: the flow field is the one place where fp32 rounding is AMPLIFIED -- a flow error of
+        # d pixels moves the bilinear tap by d, and where the tap straddles the image border the warped feature changes by
+        # d x |feature| (hundreds), i.e. 1e-5 px is 1e-3 on a logit.  Every layer that feeds the flow input of a warp therefore
+        # stays off the Winograd-on-bf16 launch geometries (41 / 42; about 3x the rounding error of a direct evaluation):
+        # measured at 1024x2048, non-key frame, pixel (632, 2039): 1.0e-3 with them, 4.0e-4 without (scripts/debug/wb3_budget.py).
+        self.flow_ancestors = set()
+        stack = []
+        for n_ in self.nodes:
+            if n_.op == "GridGenerator":
+                stack.append(n_.inputs[0])
+            elif n_.op == "Custom" and len(n_.inputs) == 2:
+                stack.append(n_.inputs[1])
+        while stack:
+            m_ = stack.pop()
+            if id(m_) in self.flow_ancestors:
+                continue
+            self.flow_ancestors.add(id(m_))
+            stack.extend(m_.inputs)
         self.heads = sym._heads()
         self.head_ids = set(id(h) for h in self.heads)
         self.ops = []          # (kind, dict, [views read], [views written])
@@ -495,6 +513,8 @@ class Lowering(object):
                          "p": "%d,%d" % a["pad"], "d": "%d,%d" % a["dilate"]})
             reads.append(xin)
             flops = 2.0 * ho * wo * cout * cin * a["kernel"][0] * a["kernel"][1]
+        if id(A) in self.flow_ancestors:
+            args["wb3"] = 0
         if bias:
             args["bias"] = bias
         if bn is not None:

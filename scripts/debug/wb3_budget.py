@@ -30,5 +30,6 @@ for skip in sys.argv[1:] or [""]:
     es = []
     for (lg, lab), (rlg, rlab) in zip(outs, ref):
         e = np.abs(np.asarray(lg) - np.asarray(rlg))
-        es.append((float(e.max()), int((e > 1e-3).sum()), float(np.abs(rlg).max())))
-    print("skip=%-24r" % skip, " ".join("e=%.3g (n>1e-3: %d, |logit| %.0f)" % t for t in es), flush=True)
+        at = np.unravel_index(int(e.argmax()), e.shape)
+        es.append((float(e.max()), int((e > 1e-3).sum()), float(np.abs(rlg).max()), int(at[-2]), int(at[-1])))
+    print("skip=%-24r fold=%s" % (skip, os.environ.get("ACCEL_FOLD_LINEAR", "1")), " ".join("e=%.3g (n>1e-3: %d, |logit| %.0f, at %d,%d)" % t for t in es), flush=True)

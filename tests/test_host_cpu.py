@@ -678,3 +678,20 @@ def test_reference_experiment_configs_drop_in_unchanged():
             text, lw = lower.lower(sym, shapes)
             assert lw.total_flops > 0 and "score_tail" in text
     reset_config()
+
+
+def test_flow_field_layers_stay_off_the_winograd_bf16_geometries(demo_cfg):
+    """Accuracy budget (accel_amd/lower.py): every convolution that feeds the flow input of the warp carries wb3=0
+    (launch geometries 41 / 42 withheld), and no layer of the two ResNet branches does."""
+    from accel_amd import lower
+    from accel_amd.symbols import accel_18
+    H, W = 256, 512
+    sym = accel_18.accel_18().get_cur_test_symbol(demo_cfg)
+    text, _ = lower.lower(sym, {"data": (1, 3, H, W), "data_key": (1, 3, H, W), "feat_key": (1, 2048, H // 16, W // 16)})
+    tagged, free = set(), set()
+    for line in text.split("\n"):
+        if line.startswith("conv"):
+            name = [t for t in line.split() if t.startswith("name=")][0][5:]
+            (tagged if "wb3=0" in line.split() else free).add(name)
+    assert {"conv3_1", "conv4_1", "conv5_1", "conv6_1", "flow_conv1", "Convolution5"} <= tagged
+    assert all(not n.startswith("18_") for n in tagged) and any(n.startswith("18_") for n in free)
