@@ -145,11 +145,13 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         rr_off = ((2 * tyl) * RW + pxx) * 16 + ((q ^ (((pxx >> 1) & 1) << 1)) << 2);      // row r: + r * RW * 16; quad q + 2: ^ 8
     }
     auto load_g = [&](int k) {
+        if constexpr ((VAR & 8) != 0) return;
         const unsigned ko = (unsigned)(kb + min(k, nk - 1)) * (BKC * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = buf_load4(xr, g_off[i] != OOB ? g_off[i] + ko : OOB);
     };
     auto store_g = [&]() {
+        if constexpr ((VAR & 8) != 0) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(rawS + g_dst[i]) = g[i];
     };
@@ -557,8 +559,22 @@ hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_
         return hipSuccess;
     };
     hipError_t le;
-    if (union_loader) le = go(&conv_wino_b3_kernel<0, true>);
-    else {
+    if (union_loader) {
+#ifdef ACCEL_CONV_DIAG
+        static int uvar = -1;
+        if (uvar < 0) { const char* e = getenv("ACCEL_WB3_VARIANT"); uvar = e ? atoi(e) : 0; }
+        switch (uvar) {
+            case 3: le = go(&conv_wino_b3_kernel<3, true>); break;        // no MFMAs
+            case 5: le = go(&conv_wino_b3_kernel<5, true>); break;        // no weight loads
+            case 9: le = go(&conv_wino_b3_kernel<9, true>); break;        // no patch loads, raw copy, transform, V stores
+            case 13: le = go(&conv_wino_b3_kernel<13, true>); break;      // MFMAs + fragment reads + split + barriers
+            case 31: le = go(&conv_wino_b3_kernel<31, true>); break;      // barriers + fragment reads + epilogue only
+            default: le = go(&conv_wino_b3_kernel<0, true>); break;
+        }
+#else
+        le = go(&conv_wino_b3_kernel<0, true>);
+#endif
+    } else {
 #ifdef ACCEL_CONV_DIAG
     // timing-only ablations (WRONG results by design; diagnostics build only): ACCEL_WB3_VARIANT = sum of the VAR bits
     static int var = -1;
