@@ -11,13 +11,12 @@ rocprofv3 -L > $OUT/avail.txt 2>&1
 CMD="python $REPO/scripts/microbench/bench_conv.py $T"
 WINO=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/p1 -o w --output-format csv -- $CMD > $OUT/p1.log 2>&1
 WINO=1 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT -d $OUT/p2 -o w --output-format csv -- $CMD > $OUT/p2.log 2>&1
-WINO=1 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum -d $OUT/p3 -o w --output-format csv -- $CMD > $OUT/p3.log 2>&1
-WINO=1 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $OUT/p4 -o w --output-format csv -- $CMD > $OUT/p4.log 2>&1
+# (a third pass with TCP_* / TA_* counters hung the profiler on this stack for the full time limit: not collected)
 cd $REPO
 python - <<'PY'
 import csv, glob, collections, os
 out = os.environ.get("OUT", "gpurun_out/wb3_pmc")
-for p in ("p1", "p2", "p3", "p4"):
+for p in ("p1", "p2"):
     fs = glob.glob("%s/%s/**/*counter_collection.csv" % (out, p), recursive=True)
     if not fs:
         print(p, "no csv;", open("%s/%s.log" % (out, p)).read()[-600:])
