@@ -71,6 +71,11 @@ struct HostParam {
 struct DevBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
+    // accel_model_bind_device: input buffers that only the prep kernels read are read THROUGH `slot` (a pointer in device
+    // memory, initially = ptr), which the host may point at a caller-owned frame between two runs of a captured plan
+    const void** slot = nullptr;
+    const void* bound = nullptr;        // what the slot points at when it is not `ptr`
+    int readers = 0, prep_readers = 0;  // plan operands resolved to this buffer / those of prep_rgb and prep_flow
 };
 
 struct accel_model {
@@ -129,6 +134,8 @@ struct Op {
     BufRef a, b, c, d;          // generic buffer slots
     const float* p0 = nullptr;  // generic device param slots
     const float* p1 = nullptr;
+    const float* const* slot_a = nullptr;   // prep ops: pointer slots of the image inputs (accel_model_bind_device)
+    const float* const* slot_b = nullptr;
     size_t nbytes = 0;
     int H = 0, W = 0;
     int stream = 0;             // 0 = compute stream, 1 = side stream
@@ -343,6 +350,7 @@ static int resolve(accel_plan* p, BufRef& r, const char* what)
         auto it = p->m->pbufs.find(r.space);
         if (it == p->m->pbufs.end()) return fail(ACCEL_ERR_PLAN, "buffer '%s': unknown persistent buffer '%s'", what, r.space.c_str());
         r.ptr = reinterpret_cast<float*>(static_cast<char*>(it->second.ptr) + r.off);
+        ++it->second.readers;
     }
     if (r.space == "A" && (r.Cs % 4 || (r.off % 16))) return fail(ACCEL_ERR_PLAN, "buffer '%s': Cs %d / offset %zu not 16-byte aligned", what, r.Cs, r.off);
     return 0;
@@ -737,6 +745,23 @@ static int upload_param(accel_plan* p, const std::string& name, size_t expect, c
     return 0;
 }
 
+// the pointer slot of a whole persistent input buffer read by a prep kernel (null for arena views and partial views)
+static int input_slot(accel_plan* p, const BufRef& r, const float* const** out)
+{
+    *out = nullptr;
+    if (r.space == "A" || r.off != 0) return 0;
+    DevBuf& b = p->m->pbufs[r.space];
+    ++b.prep_readers;
+    if (!b.slot) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(void*)));
+        b.slot = static_cast<const void**>(d);
+        HIP_TRY(hipMemcpy(d, &b.ptr, sizeof(void*), hipMemcpyHostToDevice));
+    }
+    *out = reinterpret_cast<const float* const*>(b.slot);
+    return 0;
+}
+
 static int finalize_op(accel_plan* p, Op& op)
 {
     const KV& kv = op.kv;
@@ -747,6 +772,7 @@ static int finalize_op(accel_plan* p, Op& op)
     case OP_PREP_RGB: {
         if ((rc = parse_buf(kv, "src", op.a)) || (rc = parse_buf(kv, "dst", op.b))) return rc;
         if ((rc = resolve(p, op.a, "src")) || (rc = resolve(p, op.b, "dst"))) return rc;
+        if ((rc = input_slot(p, op.a, &op.slot_a))) return rc;
         op.H = (int)kv_int(kv, "H"); op.W = (int)kv_int(kv, "W");
         if (op.b.Cs != 4) return fail(ACCEL_ERR_PLAN, "prep_rgb: dst must be NHWC4");
         if (kv_has(kv, "bn")) {
@@ -761,6 +787,7 @@ static int finalize_op(accel_plan* p, Op& op)
     case OP_PREP_FLOW: {
         if ((rc = parse_buf(kv, "cur", op.a)) || (rc = parse_buf(kv, "prev", op.b)) || (rc = parse_buf(kv, "dst", op.c))) return rc;
         if ((rc = resolve(p, op.a, "cur")) || (rc = resolve(p, op.b, "prev")) || (rc = resolve(p, op.c, "dst"))) return rc;
+        if ((rc = input_slot(p, op.a, &op.slot_a)) || (rc = input_slot(p, op.b, &op.slot_b))) return rc;
         op.H = (int)kv_int(kv, "H"); op.W = (int)kv_int(kv, "W");
         if (op.c.Cs != 8 || (op.H & 1) || (op.W & 1)) return fail(ACCEL_ERR_PLAN, "prep_flow: dst must be NHWC8 and H,W even");
         return 0;
@@ -896,8 +923,8 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
     // batch: blockIdx.z = image for the byte movers (fixed stride between images), M = N*Ho*Wo inside the convolution
-    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, op.b.N, st); break;
-    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, op.c.N, st); break;
+    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, op.b.N, st, op.slot_a); break;
+    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, op.c.N, st, op.slot_a, op.slot_b); break;
     case OP_POOL: {
         PoolParams q = op.pool;
         q.N = op.a.N; q.x_img = op.a.img(); q.y_img = op.b.img();
@@ -1309,7 +1336,7 @@ extern "C" int accel_model_destroy(accel_model* m)
     if (!m) return 0;
     hipStreamSynchronize(m->ctx->stream);
     for (accel_plan* p : m->plans) plan_free(p);
-    for (auto& kv : m->pbufs) hipFree(kv.second.ptr);
+    for (auto& kv : m->pbufs) { hipFree(kv.second.ptr); if (kv.second.slot) hipFree(const_cast<void**>(kv.second.slot)); }
     for (auto& kv : m->shadows) { if (kv.second.ready) hipEventDestroy(kv.second.ready); if (kv.second.consumed) hipEventDestroy(kv.second.consumed); hipFree(kv.second.ptr); }
     delete m;
     return 0;
@@ -1541,12 +1568,38 @@ extern "C" int accel_plan_arena_read(accel_plan* p, size_t offset, void* host_ds
     return 0;
 }
 
+// a write into the model's own buffer ends a binding made by accel_model_bind_device
+static int unbind(accel_model* m, DevBuf& b)
+{
+    if (!b.bound) return 0;
+    HIP_TRY(launch_set_slot(b.slot, b.ptr, m->ctx->stream));
+    b.bound = nullptr;
+    return 0;
+}
+
+extern "C" int accel_model_bind_device(accel_model* m, const char* buf, const void* devptr, size_t bytes)
+{
+    if (!m || !buf || !devptr) return fail(ACCEL_ERR_ARG, "accel_model_bind_device: NULL argument");
+    auto it = m->pbufs.find(buf);
+    if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_bind_device: unknown buffer '%s'", buf);
+    DevBuf& b = it->second;
+    if (!b.slot || b.readers != b.prep_readers)
+        return fail(ACCEL_ERR_ARG, "accel_model_bind_device: '%s' is not an image input of the finalized plans (only buffers that prep_rgb / "
+                                   "prep_flow alone read can be bound)", buf);
+    if (bytes != b.bytes) return fail(ACCEL_ERR_ARG, "accel_model_bind_device: %zu bytes, buffer '%s' has %zu", bytes, buf, b.bytes);
+    if (b.bound != devptr) HIP_TRY(launch_set_slot(b.slot, devptr, m->ctx->stream));
+    b.bound = devptr == b.ptr ? nullptr : devptr;
+    m->source_written(buf);
+    return 0;
+}
+
 extern "C" int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device)
 {
     if (!m || !buf || !src) return fail(ACCEL_ERR_ARG, "accel_model_write: NULL argument");
     auto it = m->pbufs.find(buf);
     if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_write: unknown buffer '%s'", buf);
     if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_write: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
+    if (int rc = unbind(m, it->second)) return rc;
     HIP_TRY(hipMemcpyAsync(it->second.ptr, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->ctx->stream));
     if (!src_on_device) HIP_TRY(hipStreamSynchronize(m->ctx->stream));   // pageable source may be reused by the caller
     m->source_written(buf);
@@ -1627,6 +1680,7 @@ extern "C" int accel_model_commit(accel_model* m, const char* buf)
     auto sh = m->shadows.find(buf);
     if (sh == m->shadows.end() || !sh->second.filled) return fail(ACCEL_ERR_ARG, "accel_model_commit: nothing was prefetched for '%s'", buf);
     HIP_TRY(hipStreamWaitEvent(m->ctx->stream, sh->second.ready, 0));
+    if (int rc = unbind(m, m->pbufs[buf])) return rc;
     HIP_TRY(hipMemcpyAsync(m->pbufs[buf].ptr, sh->second.ptr, sh->second.filled, hipMemcpyDeviceToDevice, m->ctx->stream));
     HIP_TRY(hipEventRecord(sh->second.consumed, m->ctx->stream));
     sh->second.was_consumed = true;

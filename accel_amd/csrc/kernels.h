@@ -98,10 +98,11 @@ size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns wo
 // NCHW fp32 3xHxW image -> NHWC4 (c3 = 0); optional per-channel scale/shift (bn_data)
 // N images: src image stride 3*H*W, dst image stride 4*H*W
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W,
-                           const float* scale3, const float* shift3, int N, hipStream_t st);
+                           const float* scale3, const float* shift3, int N, hipStream_t st, const float* const* slot = nullptr);
 // FlowNet input: avgpool2x2(concat(cur/255, prev/255)) -> NHWC8 at H/2 x W/2 (c6,c7 = 0)
 hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W,
-                            int N, hipStream_t st);
+                            int N, hipStream_t st, const float* const* cur_slot = nullptr, const float* const* prev_slot = nullptr);
+hipError_t launch_set_slot(const void** slot, const void* value, hipStream_t st);
 
 struct PoolParams {
     const float* x; float* y;

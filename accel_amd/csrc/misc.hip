@@ -12,11 +12,14 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // image boundary: NCHW 3xHxW -> NHWC4
 // ---------------------------------------------------------------------------
 // (all byte movers below: blockIdx.z = image of the batch, images a fixed stride apart)
+// `slot` (may be null): device address of a pointer the host may redirect to a caller-owned frame between two runs of a captured
+// plan (accel_model_bind_device): the image is then read where it lies, without a copy into the model's input buffer
 __global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW,
-                                const float* scale, const float* shift)
+                                const float* scale, const float* shift, const float* const* slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= HW) return;
+    if (slot) src = *slot;
     src += (size_t)blockIdx.z * 3 * HW;
     dst += (size_t)blockIdx.z * 4 * HW;
     float r = src[i], g = src[HW + i], b = src[2 * HW + i];
@@ -29,20 +32,22 @@ __global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict
 }
 
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W, const float* scale3,
-                           const float* shift3, int N, hipStream_t st)
+                           const float* shift3, int N, hipStream_t st, const float* const* slot)
 {
     const int HW = H * W;
-    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256), 1, N), dim3(256), 0, st, src, dst, HW, scale3, shift3);
+    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256), 1, N), dim3(256), 0, st, src, dst, HW, scale3, shift3, slot);
     return hipGetLastError();
 }
 
 // FlowNet input: Concat(cur/255, prev/255) -> avg pool 2x2/2  (ref get_flownet :1752-1753)
 __global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
-                                 float* __restrict__ dst, int H, int W)
+                                 float* __restrict__ dst, int H, int W, const float* const* cur_slot, const float* const* prev_slot)
 {
     const int Wo = W >> 1, Ho = H >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ho * Wo) return;
+    if (cur_slot) cur = *cur_slot;
+    if (prev_slot) prev = *prev_slot;
     const int oy = i / Wo, ox = i - oy * Wo;
     const size_t HW = (size_t)H * W;
     cur += blockIdx.z * 3 * HW; prev += blockIdx.z * 3 * HW;
@@ -63,10 +68,11 @@ __global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __r
     d[1] = make_float4(o[4], o[5], o[6], o[7]);
 }
 
-hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, int N, hipStream_t st)
+hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, int N, hipStream_t st,
+                            const float* const* cur_slot, const float* const* prev_slot)
 {
     const int n = (H / 2) * (W / 2);
-    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256), 1, N), dim3(256), 0, st, cur, prev, dst, H, W);
+    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256), 1, N), dim3(256), 0, st, cur, prev, dst, H, W, cur_slot, prev_slot);
     return hipGetLastError();
 }
 
@@ -684,5 +690,13 @@ hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* rig
 {
     hipLaunchKernelGGL(score_fuse_lowres_kernel, dim3(cdiv((long)npix * zCs, 256)), dim3(256), 0, st, left, lCs, right, rCs,
                        cw, z, zCs, ncls, npix);
+    return hipGetLastError();
+}
+
+// one pointer written from a kernel argument: stream-ordered, no host staging buffer to keep alive
+__global__ void set_slot_kernel(const void** slot, const void* value) { *slot = value; }
+hipError_t launch_set_slot(const void** slot, const void* value, hipStream_t st)
+{
+    hipLaunchKernelGGL(set_slot_kernel, dim3(1), dim3(1), 0, st, slot, value);
     return hipGetLastError();
 }

@@ -61,6 +61,7 @@ def _declare(lib):
         "accel_plan_run_serial": [vp],
         "accel_plan_arena_read": [vp, sz, vp, sz, c.POINTER(sz)],
         "accel_model_write": [vp, c.c_char_p, vp, sz, i],
+        "accel_model_bind_device": [vp, c.c_char_p, vp, sz],
         "accel_model_read": [vp, c.c_char_p, vp, sz, i],
         "accel_model_buffer": [vp, c.c_char_p, c.POINTER(vp), c.POINTER(sz)],
         "accel_model_buffer_generation": [vp, c.c_char_p, c.POINTER(c.c_uint64)],
@@ -383,6 +384,12 @@ class Model(object):
     def write_device(self, buf, dev_ptr, nbytes):
         self.__dict__.get("_resident", {}).pop(buf, None)
         check(lib().accel_model_write(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
+
+    def bind_device(self, buf, dev_ptr, nbytes):
+        """zero-copy input (accel_model_bind_device): the plans read the image input `buf` from the caller's HBM buffer until the
+        next write / bind; the caller keeps that buffer alive and unchanged until the runs have completed"""
+        self.__dict__.get("_resident", {}).pop(buf, None)
+        check(lib().accel_model_bind_device(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes))
 
     def read(self, buf, shape, dtype=np.float32):
         out = np.empty(shape, dtype)

@@ -106,6 +106,13 @@ int accel_plan_arena_read(accel_plan* p, size_t offset, void* host_dst, size_t b
  * (:18-27) and get_outputs (:357-378) */
 int accel_model_write(accel_model* m, const char* buf, const void* src, size_t bytes, int src_on_device);
 int accel_model_read(accel_model* m, const char* buf, void* dst, size_t bytes, int dst_on_device);
+/* Zero-copy input: the image input `buf` (`data`, `data_key` -- a buffer that only the input-conversion kernels of the
+ * finalized plans read) is read from the caller's device buffer `devptr` (`bytes` = the size of `buf`, same layout) by every
+ * plan run that follows, until the next accel_model_write / accel_model_commit into `buf` or the next bind.  Stream-ordered
+ * on the context stream like a write; the caller keeps `devptr` alive and unchanged until those runs have completed.  This is
+ * what an MXNet executor does when the bound input NDArray already lives on the device (executor_group.py:18-27 copies only
+ * when source and destination differ); bench.py uses it for frames that are resident in HBM. */
+int accel_model_bind_device(accel_model* m, const char* buf, const void* devptr, size_t bytes);
 int accel_model_buffer(accel_model* m, const char* buf, void** dev_ptr, size_t* bytes);
 /* Write generation of a persistent buffer: starts at 0, bumped by every accel_plan_run of a plan that writes the
  * buffer, every accel_model_write / accel_model_commit into it and every raw-pointer hand-out.  A device handle to an
