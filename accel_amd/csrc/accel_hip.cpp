@@ -676,7 +676,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                     a0_ = e_ + 1;
                 }
             }
-            const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U;
+            const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S;
             if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0') && wb3_ok) || wb3_forced) && !c.f16 && conv_wino_b3_eligible(c)) {
                 // the same transformed weights as three exact bf16 planes in MFMA fragment order: launch geometry 41
                 std::vector<unsigned short> ub;
@@ -686,7 +686,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 c.wub = db;
                 c.wub_bytes = (unsigned)(ub.size() * sizeof(unsigned short));
             }
-        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U) {
+        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
                                        "size and channels in multiples of 8 only", op.name.c_str());
         }
@@ -1022,7 +1022,7 @@ static int g_tune_hits = 0, g_tune_timed = 0;     // decisions replayed from a t
 // A file whose version tag differs from ACCEL_TUNE_VERSION (the tile-id set changed) is ignored.
 // ACCEL_TUNE_SHIPPED=0 skips the shipped table (used when regenerating it), ACCEL_AUTOTUNE=0 disables timing altogether
 // (static heuristic for every shape that is in neither file).
-#define ACCEL_TUNE_VERSION "accel_hip-tune-8"
+#define ACCEL_TUNE_VERSION "accel_hip-tune-9"
 
 static std::string lib_dir()
 {
@@ -1134,7 +1134,7 @@ static int autotune_plan(accel_plan* p)
                 if (base) cs.push_back({CONV_TILE_WINO, 0, 1});
             }
             if (c.wub && !c.f16) {
-                for (int wt : {CONV_TILE_WINO_B3, CONV_TILE_WINO_B3U}) {
+                for (int wt : {CONV_TILE_WINO_B3, CONV_TILE_WINO_B3U, CONV_TILE_WINO_B3S}) {
                     cs.push_back({wt, 0, 0});
                     ConvParams q = c;
                     const size_t base = conv_apply(q, wt, 0, 0);

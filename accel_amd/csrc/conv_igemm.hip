@@ -1126,7 +1126,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
            (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5);
 }
 
@@ -1172,9 +1172,9 @@ size_t conv_plan_split(ConvParams& p)
         if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
         return (size_t)p.ksplit * p.M * p.Cout_store * sizeof(float);
     }
-    if (tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U) {
+    if (tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S) {
         // conv_wino_b3.hip: blocks of 64 tiles x 64 channels, K steps of 16 channels; raw partial outputs as for tile 40
-        const long blocks = (tile == CONV_TILE_WINO_B3U ? conv_wino_b3u_blocks(p, nullptr) : (long)((p.M / 4 + 63) / 64)) * (long)conv_wino_rows(p.Cout_store) / 64;
+        const long blocks = (tile == CONV_TILE_WINO_B3U ? conv_wino_b3u_blocks(p, nullptr) : tile == CONV_TILE_WINO_B3S ? conv_wino_b3s_blocks(p, nullptr) : (long)((p.M / 4 + 63) / 64)) * (long)conv_wino_rows(p.Cout_store) / 64;
         const int KT = p.Cin / 16, min_steps = 4;
         const int min_blocks = p.split_target > 0 ? p.split_target : 256;
         const int target = p.split_target > 0 ? p.split_target : 512;
@@ -1213,6 +1213,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
     if (p.force_tile == CONV_TILE_WINO_B3) return launch_conv_wino_b3(p, st);
     if (p.force_tile == CONV_TILE_WINO_B3U) return launch_conv_wino_b3(p, st, true);
+    if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
     if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && p.f16 == 1) {

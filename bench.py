@@ -247,7 +247,7 @@ class Workload(object):
                     by += wgt * op["bytes"]
                     ms += wgt * float(d)
                     n += wgt
-                    name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_b3_kernel" if op["tile"] in (41, 42) else "conv_wino_f32_kernel" if op["tile"] == 40
+                    name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_b3_kernel" if op["tile"] in (41, 42, 43) else "conv_wino_f32_kernel" if op["tile"] == 40
                             else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv1x1_ws_kernel" if op["tile"] == 60 else "conv_igemm_b3_kernel" if ((dtype == "bf16x3" and op["tile"] < 40) or 70 <= op["tile"] <= 81) else "conv_igemm_f16_kernel" if dtype == "f16" else "conv_igemm_f32_kernel")
                     f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
                     f[0] += wgt; f[1] += wgt * float(d); f[2] += wgt * op["flops"]; f[3] += wgt * op["bytes"]

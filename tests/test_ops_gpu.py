@@ -295,8 +295,8 @@ WINO_CASES = [
 
 
 # 41 = the same position-GEMMs on the bf16 matrix cores with three exact bf16 terms per operand (conv_wino_b3.hip);
-# 42 = 41 with rectangular tile blocks whose patch union is loaded once into an LDS copy
-@pytest.mark.parametrize("wt", [40, 41, 42])
+# 42 = 41 with rectangular tile blocks whose patch union is loaded once into an LDS copy; 43 = 42 with half the block, two per CU
+@pytest.mark.parametrize("wt", [40, 41, 42, 43])
 @pytest.mark.parametrize("N,C,K,H,W", WINO_CASES)
 def test_conv2d_winograd_matches_oracle(ctx, N, C, K, H, W, wt):
     x, w, b = rnd(50, N, C, H, W), rnd(51, K, C, 3, 3, scale=(2.0 / (C * 9)) ** 0.5), rnd(52, K)
@@ -313,12 +313,14 @@ def test_conv2d_winograd_b3_equals_the_fp32_winograd_kernel_to_rounding(ctx):
     for (N, C, K, H, W) in ((1, 256, 256, 16, 32), (2, 64, 64, 32, 32), (1, 512, 128, 8, 16)):
         x, w, b = rnd(53, N, C, H, W, scale=3.0), rnd(54, K, C, 3, 3, scale=(2.0 / (C * 9)) ** 0.5), rnd(55, K)
         a, bb, cc = ctx.conv2d(x, w, b, 1, 1, 1, tile=40), ctx.conv2d(x, w, b, 1, 1, 1, tile=41), ctx.conv2d(x, w, b, 1, 1, 1, tile=42)
+        dd = ctx.conv2d(x, w, b, 1, 1, 1, tile=43)
+        assert float(np.abs(bb - dd).max()) <= 2e-6 * max(1.0, float(np.abs(a).max())), (N, C, K)
         assert float(np.abs(a - bb).max()) <= 4e-6 * max(1.0, float(np.abs(a).max())), (N, C, K)
         # 41 and 42 differ only in how the patches reach the transform (and possibly in the split-K factor)
         assert float(np.abs(bb - cc).max()) <= 2e-6 * max(1.0, float(np.abs(a).max())), (N, C, K)
 
 
-@pytest.mark.parametrize("wt", [40, 41, 42])
+@pytest.mark.parametrize("wt", [40, 41, 42, 43])
 def test_conv2d_winograd_fused_epilogue_and_borders(ctx, wt):
     C, K, H, W = 64, 96, 20, 28
     x, w = rnd(60, 1, C, H, W), rnd(61, K, C, 3, 3, scale=0.05)
