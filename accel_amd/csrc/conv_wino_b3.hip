@@ -32,6 +32,9 @@
 #include "conv_common.h"
 
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+// chunk swizzle of the raw patch copy: chunk c of pixel column x at slot c ^ bitrev2((x >> 2) & 3).  The patch-column reads of a
+// ds_read_b128 lane group (4 consecutive tiles, alternating channel quads: pixel columns x .. x+9) then hit 16 different slots.
+#define RAW_SWZ(x) (((((x) >> 2) & 1) << 1) | (((x) >> 3) & 1))
 
 namespace {
 constexpr int TT = 64;                 // output tiles (2x2 pixels each) per block
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         }
         *reinterpret_cast<i32x4*>(aoff_lds) = i32x4{(int)a_off[0], (int)a_off[1], (int)a_off[2], (int)a_off[3]};
     }
-    // UL: the raw copy [RH x RW pixels][16 channels] fp32 behind the two V stages; chunk c of pixel (y, x) at slot c ^ (((x >> 1) & 1) << 1)
+    // UL: the raw copy [RH x RW pixels][16 channels] fp32 behind the two V stages; chunk c of pixel (y, x) at slot c ^ RAW_SWZ(x)
     // (the patch-column reads of 4 adjacent pixels x 2 chunks then hit 8 different bank groups).  Slot s = tid + 512 i of the
     // loader = (pixel s >> 2, chunk s & 3): 4 adjacent lanes fetch the 64 contiguous bytes of one pixel.
     float* rawS = smem + 2 * VSTAGE;
@@ -139,10 +142,10 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
             const int iy = 2 * uty0 - 1 + py, ix = 2 * utx0 - 1 + pxx;
             const bool ok = px < RH * RW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             g_off[i] = ok ? (unsigned)((((un * p.H + iy) * p.W + ix) * p.xCs + 4 * c) * 4) : OOB;
-            g_dst[i] = px < RH * RW ? px * 16 + ((c ^ (((pxx >> 1) & 1) << 1)) << 2) : RH * RW * 16 + lane * 4;      // slots past the rectangle: a dump row
+            g_dst[i] = px < RH * RW ? px * 16 + ((c ^ RAW_SWZ(pxx)) << 2) : RH * RW * 16 + lane * 4;      // slots past the rectangle: a dump row
         }
         const int tyl = tl >> bws, txl = tl & BWm, pxx = 2 * txl + j;
-        rr_off = ((2 * tyl) * RW + pxx) * 16 + ((q ^ (((pxx >> 1) & 1) << 1)) << 2);      // row r: + r * RW * 16; quad q + 2: ^ 8
+        rr_off = ((2 * tyl) * RW + pxx) * 16 + ((q ^ RAW_SWZ(pxx)) << 2);      // row r: + r * RW * 16; quad q + 2: ^ 8
     }
     auto load_g = [&](int k) {
         if constexpr ((VAR & 8) != 0) return;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     };
     // V image: [position][tile][16 channels] fp32, the 16-byte chunk c of a tile row at physical slot c ^ ((tile >> 1) & 3):
     // the fragment reads (32 consecutive tiles, one chunk each) and these stores are then bank-conflict free
-    const int lsw = (tl >> 1) & 3;
+    const int lsw = (tl >> 2) & 3;      // chunk swizzle of the V image: see the fragment reads
     const int v_dst0 = j * VPS + tl * BKC + ((q ^ lsw) << 2);
     const float sb = j == 1 ? 1.f : -1.f;      // column 3 is stored negated, U negated to match (conv_wino.hip)
 
@@ -194,7 +197,9 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 
     // ---- fragments ----
     const int fr = lane & 31, fh = lane >> 5;
-    const int fsw = (fr >> 1) & 3;
+    // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with the chunk of tile t at slot
+    // c ^ ((t >> 2) & 3) the 16 tiles of a group hit 16 different 16-byte slots of the 256-byte bank row
+    const int fsw = (fr >> 2) & 3;
     const int a_rd0 = fr * BKC + (((2 * fh) ^ fsw) << 2);            // channels 8h .. 8h+3 of tile fr
     const unsigned b_voff = (unsigned)((n0 + fr) * 32 + fh * 16);
     const unsigned u_pos = (unsigned)p.wino_rows * 32u;               // bytes of one position of one K step of one plane

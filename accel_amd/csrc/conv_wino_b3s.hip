@@ -13,6 +13,9 @@
 #include "conv_common.h"
 
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+// chunk swizzle of the raw patch copy: chunk c of pixel column x at slot c ^ bitrev2((x >> 2) & 3).  The patch-column reads of a
+// ds_read_b128 lane group (4 consecutive tiles, alternating channel quads: pixel columns x .. x+9) then hit 16 different slots.
+#define RAW_SWZ(x) (((((x) >> 2) & 1) << 1) | (((x) >> 3) & 1))
 
 namespace {
 constexpr int TTS = 32;                // output tiles (2x2 pixels each) per block
@@ -85,12 +88,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
             const int iy = 2 * uty0 - 1 + py, ix = 2 * utx0 - 1 + pxx;
             const bool ok = px < RH * RW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             g_off[i] = ok ? (unsigned)((((un * p.H + iy) * p.W + ix) * p.xCs + 4 * c) * 4) : OOB;
-            g_dst[i] = px < RH * RW ? px * 16 + ((c ^ (((pxx >> 1) & 1) << 1)) << 2) : RH * RW * 16 + lane * 4;
+            g_dst[i] = px < RH * RW ? px * 16 + ((c ^ RAW_SWZ(pxx)) << 2) : RH * RW * 16 + lane * 4;
         }
     }
     const int tyl = tl >> bws, txl = tl & BWm, pxx_t = 2 * txl + j;
-    const int rr_off = ((2 * tyl) * RW + pxx_t) * 16 + ((q ^ (((pxx_t >> 1) & 1) << 1)) << 2);
-    const int lsw = (tl >> 1) & 3;
+    const int rr_off = ((2 * tyl) * RW + pxx_t) * 16 + ((q ^ RAW_SWZ(pxx_t)) << 2);
+    const int lsw = (tl >> 2) & 3;      // chunk swizzle of the V image: see the fragment reads
     const int v_dst0 = j * VPSS + tl * BKS + ((q ^ lsw) << 2);
     const float sb = j == 1 ? 1.f : -1.f;
     auto load_g = [&](int k) {
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 
     // ---- fragments ----
     const int fr = lane & 31, fh = lane >> 5;
-    const int fsw = (fr >> 1) & 3;
+    // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with the chunk of tile t at slot
+    // c ^ ((t >> 2) & 3) the 16 tiles of a group hit 16 different 16-byte slots of the 256-byte bank row
+    const int fsw = (fr >> 2) & 3;
     const int a_rd0 = fr * BKS + (((2 * fh) ^ fsw) << 2);
     const unsigned b_voff = (unsigned)((n0 + fr) * 32 + fh * 16);
     const unsigned u_pos = (unsigned)p.wino_rows * 32u;
