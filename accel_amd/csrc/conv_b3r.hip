@@ -232,25 +232,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     load_a(0, (kt_begin + 1) * BK);
     // The scheduler sinks the weight / pixel requests to their first use unless fenced.  Keeping them where the pipeline wants
     // them pays on the 2x4 grid of 128x128 and on the 1x8 grid (1-3 %, up to 10 % on the 64-column layers) and costs 2-6 % on the
-    // others (profiles/r03_wino_b3/b3r_fence.log vs b3r_nofence.log): decided per geometry.
-    constexpr bool FENCED = (BM == 128 && BN == 128 && WGM == 2 && WGN == 4) || WGN == 8;
-#define B3R_FENCE() do { if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0); } while (0)
+    // others (profiles/r03_wino_b3/b3r_fence.log vs b3r_nofence.log; single fences: b3r_p*.log): decided per geometry.
+    // bit 0: behind the first weight request, bit 1: behind the stage of the next pixel tile, bit 2: behind the mid-step requests
+    constexpr int FENCES = ((BM == 128 && BN == 128 && WGM == 2 && WGN == 4) || WGN == 8) ? 7      // 76, 80: all three
+                           : (BN == 256 && WGM == 2) ? 1                                             // 79: the first only (-1 %)
+                           : (BN == 128 && WGM == 1) ? 4 : 0;                                        // 81: the last only (-0.5 %)
+#define B3R_FENCE_N(n) do { if constexpr ((FENCES & (n)) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
     for (int k = 0; k < nk; ++k) {
         const int cur = k & 1, ks = kt_begin + k;
         load_b(2 * ks + 1, 1);
-        B3R_FENCE();
+        B3R_FENCE_N(1);
         read_fa(cur, 0, 0);
         mma(0, 0);
         store_a(cur ^ 1, 0);
-        B3R_FENCE();
+        B3R_FENCE_N(2);
         load_a(0, (ks + 2) * BK);
         load_b(2 * ks + 2, 0);
-        B3R_FENCE();
+        B3R_FENCE_N(4);
         read_fa(cur, 1, 0);
         mma(0, 1);
         if constexpr ((ABL & 16) == 0) __syncthreads();
     }
-#undef B3R_FENCE
+#undef B3R_FENCE_N
     conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 }
 
