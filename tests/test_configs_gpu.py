@@ -50,6 +50,34 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
     check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
 
 
+@pytest.mark.parametrize("geometry", [41, 42, 43])
+def test_winograd_bf16_geometry_on_every_eligible_layer_vs_oracle(demo_cfg, monkeypatch, tmp_path, geometry):
+    """The launch-geometry table decides per layer; this test does not depend on what it decided: EVERY layer that can take
+    the Winograd-on-bf16 geometry 41 / 42 / 43 (every 3x3 / stride 1 layer of the two ResNet branches with channels in
+    multiples of 16 -- the FlowNet layers are withheld by the lowering) is forced onto it (ACCEL_WB3_FORCE,
+    a private tune cache so that nothing is replayed), and a key + a non-key frame of Accel-18 at 512x1024 are compared with
+    the oracle at the whole-graph tolerance."""
+    from accel_amd import demo
+    from accel_amd.core import tester
+    monkeypatch.setenv("ACCEL_WB3_FORCE", str(geometry))
+    monkeypatch.setenv("ACCEL_TUNE_CACHE", str(tmp_path / "forced.tune"))
+    H, W, interval = 512, 1024, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 2)
+    try:
+        outs = demo.run_clip("18", demo_cfg, arg, aux, frames, interval)
+        from accel_amd import runtime
+        forced = [l for l in open(str(tmp_path / "forced.tune")) if not l.startswith("#") and int(l.split()[16]) == geometry]
+        assert len(forced) >= 8, "the forced geometry must have been applied to the 3x3 layers (%d table lines)" % len(forced)
+    finally:
+        tester.release_models()
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    check_against_oracle(outs, ref, "accel-18 512x1024 every eligible layer on geometry %d" % geometry)
+
+
 def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkeypatch):
     """What bench.py times: one call = one frame of each of 8 independent clips at 1024x2048.  Image b of the batched
     call must reproduce the batch-1 run of clip b over a key and a non-key frame (tile choices differ between the two
