@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     // Measured and NOT adopted (profiles/r03_b3r_microbench.md): the pixel loads behind the weight loads (-4 %); weight
     // fragments four half steps and pixel tiles two K steps ahead (no gain, spills at 128 registers); the barrier moved to
     // the middle of the step with every LDS fragment read issued half a step early (no gain, spills).
+    // Repeated at the end of round 3 WITH the requests fenced in place (four weight buffers, every half step requested a whole K
+    // step ahead, loop unrolled by two for the buffer parity): +-1 % on geometries 76 and 80 (profiles/r03_wino_b3/b3r_d*.log) --
+    // request latency is not what binds this kernel.
     load_a(0, kt_begin * BK);
     load_b(2 * kt_begin, 0);
     store_a(0, 0);
