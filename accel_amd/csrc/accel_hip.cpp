@@ -541,7 +541,7 @@ static int finalize_conv(accel_plan* p, Op& op)
         // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_BF16X3=0 withholds it)
         const char* be = getenv("ACCEL_BF16X3");
         const int ft = (int)kv_int(kv, "tile", -1);
-        const bool forced = (ft >= CONV_TILE_B3 && ft < CONV_TILE_B3 + 12) || (ft >= 90 && ft <= 96);
+        const bool forced = (ft >= CONV_TILE_B3 && ft < CONV_TILE_B3D + CONV_TILE_B3D_N) || (ft >= 90 && ft <= 96);
         if (!c.f16 && c.Cin % 4 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
             std::vector<uint16_t> pb;
             pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
@@ -549,14 +549,14 @@ static int finalize_conv(accel_plan* p, Op& op)
             if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
             c.wb3 = d3;
             const char* re_ = getenv("ACCEL_B3R");
-            const bool forced_r = (ft >= CONV_TILE_B3R && ft < CONV_TILE_B3R + 6) || (ft >= 90 && ft <= 96);
+            const bool forced_r = (ft >= CONV_TILE_B3R && ft < CONV_TILE_B3D + CONV_TILE_B3D_N) || (ft >= 90 && ft <= 96);
             if (!(re_ && re_[0] == '0') || forced_r) {      // the fragment-ordered copy for the second-generation kernel
                 pack_bf16x3r(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
                 void* d4 = nullptr;
                 if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d4))) return rc;
                 c.wb3r = d4;
             }
-        } else if (forced && !(c.f16 == 1 && c.wb3r && ft >= CONV_TILE_B3R && ft < CONV_TILE_B3R + 6)) {
+        } else if (forced && !(c.f16 == 1 && c.wb3r && ft >= CONV_TILE_B3R && ft < CONV_TILE_B3D + CONV_TILE_B3D_N)) {
             return fail(ACCEL_ERR_ARG, "conv %s: the bf16x3 kernel takes layers with more than "
                                        "4 output channels only", op.name.c_str());
         }
@@ -1148,11 +1148,16 @@ static int autotune_plan(accel_plan* p)
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
-                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
+                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5,
+                                        CONV_TILE_B3D, CONV_TILE_B3D + 1, CONV_TILE_B3D + 2, CONV_TILE_B3D + 3, CONV_TILE_B3D + 4, CONV_TILE_B3D + 5};
+            const char* nb3d = getenv("ACCEL_B3D");
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && t < CONV_TILE_B3R && !nb3) continue;
                 if (t >= CONV_TILE_B3R && !c.wb3r) continue;
+                // conv_b3d.hip (both operands by LDS-DMA): measured within +-2 % of the best conv_b3r geometry on every fp32 layer of the
+                // step (profiles/r04_b3d_microbench.log), so it is offered to the tuner only on request (ACCEL_B3D=1); forced geometry ids work
+                if (t >= CONV_TILE_B3D && (!(nb3d && nb3d[0] == '1') || !conv_b3d_eligible(c) || (c.f16 == 1 && t > CONV_TILE_B3D + 3))) continue;
                 if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 if (c.f16 && !(t <= 3 || t == 10 || (c.f16 == 1 && t >= CONV_TILE_B3R && c.wb3r))) continue;
@@ -1518,6 +1523,14 @@ extern "C" int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit
     return 0;
 }
 
+extern "C" int accel_plan_op_mode(accel_plan* p, int i, int* mode)
+{
+    if (!p || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_mode: index out of range");
+    const Op& op = p->ops[i];
+    if (mode) *mode = op.kind == OP_CONV ? op.conv.f16 : -1;
+    return 0;
+}
+
 extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
 {
     if (!p || !p->finalized || !ms || n_ms < (int)p->ops.size() || iters < 1) return fail(ACCEL_ERR_ARG, "accel_plan_profile: bad argument");
@@ -1612,7 +1625,9 @@ extern "C" int accel_model_read(accel_model* m, const char* buf, void* dst, size
     auto it = m->pbufs.find(buf);
     if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_read: unknown buffer '%s'", buf);
     if (bytes > it->second.bytes) return fail(ACCEL_ERR_ARG, "accel_model_read: %zu bytes > buffer '%s' (%zu)", bytes, buf, it->second.bytes);
-    HIP_TRY(hipMemcpyAsync(dst, it->second.ptr, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
+    // a bound input is read where the plans read it (the caller's frame), not the model-owned copy an earlier write left behind
+    const void* src = it->second.bound ? it->second.bound : it->second.ptr;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, m->ctx->stream));
     if (!dst_on_device) HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     return 0;
 }
@@ -1622,6 +1637,9 @@ extern "C" int accel_model_buffer(accel_model* m, const char* buf, void** dev_pt
     if (!m || !buf) return fail(ACCEL_ERR_ARG, "accel_model_buffer: NULL argument");
     auto it = m->pbufs.find(buf);
     if (it == m->pbufs.end()) return fail(ACCEL_ERR_ARG, "accel_model_buffer: unknown buffer '%s'", buf);
+    // the caller is about to write the model-owned buffer through the raw pointer: a binding made by accel_model_bind_device
+    // ends here (the plans read the model's copy again), otherwise that write would be silently ignored
+    if (dev_ptr) if (int rc = unbind(m, it->second)) return rc;
     if (dev_ptr) *dev_ptr = it->second.ptr;
     if (bytes) *bytes = it->second.bytes;
     if (dev_ptr) m->source_written(buf);   // the caller may write through the raw pointer: derived buffers become stale
@@ -2101,6 +2119,14 @@ struct accel_comm {
         if (r__ != 0) return fail(ACCEL_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r__) : "?"); \
     } while (0)
 
+extern "C" int accel_comm_available(void)
+{
+    const char* off = getenv("ACCEL_RCCL_UNAVAILABLE");      // tests: this rank behaves as if librccl could not be loaded
+    if (off && off[0] == '1') return fail(ACCEL_ERR_COMM, "librccl withheld by ACCEL_RCCL_UNAVAILABLE=1");
+    if (!rccl().ok) return fail(ACCEL_ERR_COMM, "%s", rccl().why.c_str());
+    return 0;
+}
+
 extern "C" int accel_comm_unique_id(void* id128)
 {
     if (!id128) return fail(ACCEL_ERR_ARG, "accel_comm_unique_id: NULL argument");
@@ -2154,9 +2180,20 @@ extern "C" int accel_comm_destroy(accel_comm* c)
     return 0;
 }
 
+extern "C" int accel_gather_frames(accel_comm* c, const void* sendbuf, size_t send_bytes, void* recvbuf_or_null, size_t bytes, int root);
+
 extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* recvbuf_or_null, size_t bytes, int root)
 {
-    if (!c || !sendbuf || !bytes) return fail(ACCEL_ERR_ARG, "accel_gather_logits: bad argument");
+    return accel_gather_frames(c, sendbuf, bytes, recvbuf_or_null, bytes, root);
+}
+
+// `bytes` = the slot every rank owns in the root's receive buffer; a PEER always fills its slot (send_bytes == bytes: the root
+// posts its receives with that count), the ROOT may contribute fewer bytes (a root that is given fewer clips because it also
+// receives everybody else's frames): its own block is a device copy of send_bytes, the rest of its slot is left untouched.
+extern "C" int accel_gather_frames(accel_comm* c, const void* sendbuf, size_t send_bytes, void* recvbuf_or_null, size_t bytes, int root)
+{
+    if (!c || !sendbuf || !bytes || !send_bytes || send_bytes > bytes) return fail(ACCEL_ERR_ARG, "accel_gather_logits: bad argument");
+    if (c->rank != root && send_bytes != bytes) return fail(ACCEL_ERR_ARG, "accel_gather_frames: only the root may send less than a full slot");
     if (root < 0 || root >= c->nranks) return fail(ACCEL_ERR_ARG, "accel_gather_logits: root %d out of range", root);
     if (c->rank == root && !recvbuf_or_null) return fail(ACCEL_ERR_ARG, "accel_gather_logits: the root needs a receive buffer");
     HIP_TRY(hipSetDevice(c->ctx->device));
@@ -2169,7 +2206,7 @@ extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* rec
     }
     // (1) compute stream: wait until the transfer issued from this slot two calls ago has left it, then refill it
     if (c->used[s]) HIP_TRY(hipStreamWaitEvent(compute, c->sent[s], 0));
-    HIP_TRY(hipMemcpyAsync(c->stage[s], sendbuf, bytes, hipMemcpyDeviceToDevice, compute));
+    HIP_TRY(hipMemcpyAsync(c->stage[s], sendbuf, send_bytes, hipMemcpyDeviceToDevice, compute));
     HIP_TRY(hipEventRecord(c->staged[s], compute));
     // (2) communication stream: point-to-point to the root, every peer over its own link; the root copies its own block
     HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[s], 0));
@@ -2185,7 +2222,7 @@ extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* rec
             RCCL_TRY(rccl().Recv(recv + (size_t)r * bytes, bytes, /*ncclUint8*/ 1, r, c->comm, c->stream));
         RCCL_TRY(rccl().GroupEnd());
     } else if (c->rank == root) {
-        HIP_TRY(hipMemcpyAsync(recv + (size_t)root * bytes, c->stage[s], bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(recv + (size_t)root * bytes, c->stage[s], send_bytes, hipMemcpyDeviceToDevice, c->stream));
         if (c->nranks > 1) {
             RCCL_TRY(rccl().GroupStart());
             for (int r = 0; r < c->nranks; ++r)

@@ -6,7 +6,9 @@
 
 // Shared tail of both conv kernels: split-K partial store or the fused epilogue
 // (scale/shift -> +residual -> activation -> store, optional dual output).
-template <int MI, int NI, int WGN>
+// RES_PER_J: the residual values are fetched one 32-column block ahead of its stores instead of all at once (tiles with 128
+// accumulator registers per lane cannot hold a second copy of them)
+template <int MI, int NI, int WGN, bool RES_PER_J = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
                                               int lane, int py, int px, int HoWo)
 {
@@ -64,7 +66,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         sc[j] = p.scale[cc]; sf[j] = p.shift[cc];
         sc2[j] = p.y2 ? p.scale2[cc] : 1.f; sf2[j] = p.y2 ? p.shift2[cc] : 0.f;
     }
-    if (p.res) {
+    if (!RES_PER_J && p.res) {
         float rv[MI][NI][16];
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -85,6 +87,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
+        if constexpr (RES_PER_J) {
+            if (p.res) {
+                float rv[MI][16];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
+                        rv[i][e] = buf_load1(rr, (cok[j] && px_ != OOB) ? (px_ * p.resCs + co[j]) * 4u : OOB);
+                    }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][e];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll

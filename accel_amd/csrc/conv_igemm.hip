@@ -1127,7 +1127,8 @@ bool conv_tile_valid(int tile)
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
     return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
-           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5);
+           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5) ||
+           (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N);
 }
 
 static void tile_dims(int tile, int& bm, int& bn)
@@ -1139,6 +1140,9 @@ static void tile_dims(int tile, int& bm, int& bn)
     if (tile == CONV_TILE_B3R + 1) { bm = 128; bn = 64; return; }
     if (tile == CONV_TILE_B3R + 3 || tile == CONV_TILE_B3R + 4) { bm = 128; bn = 256; return; }
     if (tile == CONV_TILE_B3R + 5) { bm = 128; bn = 128; return; }
+    if (tile == CONV_TILE_B3D || tile == CONV_TILE_B3D + 4) { bm = 256; bn = 256; return; }
+    if (tile == CONV_TILE_B3D + 1 || tile == CONV_TILE_B3D + 5) { bm = 128; bn = 256; return; }
+    if (tile == CONV_TILE_B3D + 2 || tile == CONV_TILE_B3D + 3) { bm = 128; bn = 128; return; }
     if (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5) { static const int g[5] = {0, 1, 2, 3, 10}; tile = g[tile - CONV_TILE_B3]; }
     if (tile >= 31 && tile <= 35) { static const int g[5] = {3, 0, 2, 1, 4}; tile = g[tile - 31]; }   // deep-prefetch variants
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
@@ -1216,6 +1220,14 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
+    if (p.force_tile >= CONV_TILE_B3D && p.force_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {
+        // conv_b3d.hip: the fragment-ordered planes of conv_b3r (bf16x3) or its one-plane fp16 form, both operands by LDS-DMA
+        if (!p.wb3r || p.f16 == 2) return hipErrorInvalidValue;
+        ConvParams q = p;
+        q.w = static_cast<const float*>(p.wb3r);
+        if (!p.f16) { q.w_bytes = p.w_bytes / 2; q.f16 = 2; }
+        return launch_conv_b3d(q, p.force_tile, st);
+    }
     if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && p.f16 == 1) {
         // fp16-MFMA mode on the staging of conv_b3r.hip: one plane of half-rounded weights in MFMA fragment order
         if (!p.wb3r) return hipErrorInvalidValue;

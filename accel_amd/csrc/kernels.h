@@ -90,6 +90,11 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
 #define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);
+#define CONV_TILE_B3D 82                 // conv_b3d.hip (both operands by LDS-DMA, pixels split after the fragment read): 82 = 256x256 / 4x2 wavefronts,
+                                         // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 86 = 256x256 / 8x1, 87 = 128x256 / 2x4
+#define CONV_TILE_B3D_N 6
+bool conv_b3d_eligible(const ConvParams& p);
+hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st);
 #define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)
 bool conv_ws_eligible(const ConvParams& p);
 size_t conv_ws_pack_floats(int Cin, int cout_store);

@@ -14,11 +14,25 @@ import os
 import numpy as np
 
 
-def shard_clips(num_clips, world_size, rank):
-    """Contiguous static partition (config 4: 64 clips -> 8 per GPU)."""
-    per = (num_clips + world_size - 1) // world_size
-    lo = min(rank * per, num_clips)
-    return list(range(lo, min(lo + per, num_clips)))
+def shard_clips(num_clips, world_size, rank, root_relief=0):
+    """Contiguous static partition (config 4: 64 clips -> 8 per GPU).
+
+    root_relief = r > 0: rank 0 -- the root of the logits gather, which besides its own frames receives everybody else's --
+    takes r clips fewer than an even share and the least loaded peers absorb them, still contiguous, disjoint and
+    complete.  With world_size 1 there is nobody to relieve."""
+    if world_size <= 1 or root_relief <= 0:
+        per = (num_clips + world_size - 1) // world_size
+        lo = min(rank * per, num_clips)
+        return list(range(lo, min(lo + per, num_clips)))
+    base = num_clips // world_size
+    sizes = [base + (1 if r < num_clips % world_size else 0) for r in range(world_size)]
+    give = min(int(root_relief), sizes[0])
+    sizes[0] -= give
+    for _ in range(give):       # to the least loaded peer (the last one among equals)
+        r = min(range(world_size - 1, 0, -1), key=lambda k: sizes[k])
+        sizes[r] += 1
+    lo = sum(sizes[:rank])
+    return list(range(lo, lo + sizes[rank]))
 
 
 def assign_videos_greedy(frame_counts, world_size):
@@ -49,19 +63,41 @@ def as_torch(ptr, shape, dtype="f4", device=0):
     return torch.as_tensor(_DevPtr(ptr, shape, {"f4": "<f4", "u1": "|u1"}[dtype]), device="cuda:%d" % device)
 
 
+def _vote_all(ok, ctx, group):
+    """collective AND of a per-rank flag over the group (every rank calls it)"""
+    import torch
+    import torch.distributed as dist
+    if dist.get_world_size(group) == 1:
+        return bool(ok)
+    dev = "cuda:%d" % ctx.device_id if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
 def make_comm(ctx, group=None):
     """RCCL communicator of the C ABI (accel_comm_create) spanning the ranks of a torch.distributed group: the 128-byte
     unique id is made on the group's first rank and handed to the others through the process group (the rendezvous
     torch.distributed already did); everything after that is libaccel_hip + librccl, no torch on the data path.
 
-    The decision is COLLECTIVE: every rank takes part in the same broadcast and the same success vote, and either all
-    ranks get a communicator or all get None (and the reason) -- a rank that cannot resolve librccl, or whose
-    ncclCommInitRank fails, never leaves the others blocked in a broadcast or in a different transport."""
-    import torch
+    The decision is COLLECTIVE, in three rounds that every rank takes part in:
+      1. every rank probes librccl itself (accel_comm_available: dlopen + the entry points, no communicator) and the ranks
+         vote -- ncclCommInitRank blocks until ALL ranks have arrived, so no rank may enter it unless every rank can;
+      2. the first rank makes the id and broadcasts it (an exception there travels as the payload);
+      3. every rank creates its communicator and the ranks vote again; a partially created set is destroyed.
+    Either all ranks get a communicator or all raise AccelError with the reason (FrameGather then falls back to the
+    torch.distributed transport on every rank alike)."""
     import torch.distributed as dist
     from . import runtime
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     src = dist.get_global_rank(group, 0) if (group is not None and hasattr(dist, "get_global_rank")) else 0
+    try:
+        mine = runtime.Comm.available()
+    except Exception as e:      # the library itself is missing
+        mine = str(e)
+    if not _vote_all(mine is None, ctx, group):
+        raise runtime.AccelError("C-ABI communicator unavailable on every rank: %s"
+                                 % (("rank %d: %s" % (rank, mine)) if mine else "another rank cannot resolve librccl"))
     box = [None]
     if rank == 0:
         try:
@@ -72,20 +108,15 @@ def make_comm(ctx, group=None):
         dist.broadcast_object_list(box, src=src, group=group)
     comm, why = None, ""
     if isinstance(box[0], Exception) or box[0] is None:
-        why = str(box[0])
+        why = str(box[0])       # the same on every rank: nobody enters ncclCommInitRank
     else:
         try:
             comm = runtime.Comm(ctx, rank, world, box[0])
         except Exception as e:
             why = "rank %d: %s" % (rank, e)
-    if world > 1:
-        backend = dist.get_backend(group)
-        dev = "cuda:%d" % ctx.device_id if backend == "nccl" else "cpu"
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm, why = None, "another rank could not create its communicator"
+    if not _vote_all(comm is not None, ctx, group) and comm is not None:
+        comm.close()
+        comm, why = None, "another rank could not create its communicator"
     if comm is None:
         raise runtime.AccelError("C-ABI communicator unavailable on every rank: %s" % (why or "unknown reason"))
     return comm
@@ -102,7 +133,9 @@ class FrameGather(object):
     transport "torch": the same protocol through torch.distributed.gather(async_op=True) (fallback when librccl
     cannot be resolved by the library; also the gloo/CPU path of the tests)."""
 
-    def __init__(self, model, ctx, what, shape, dtype, device, group=None, backend_device="cuda", transport="auto"):
+    def __init__(self, model, ctx, what, shape, dtype, device, group=None, backend_device="cuda", transport="auto", own_bytes=None):
+        """shape: what a PEER contributes per frame (the slot size at the root); own_bytes: what THIS rank contributes when that is
+        less (only the root may: accel_gather_frames; C-ABI transport only)"""
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -113,6 +146,11 @@ class FrameGather(object):
         dev = "cuda:%d" % device if backend_device == "cuda" else "cpu"
         self.on_cuda = backend_device == "cuda"
         self.nbytes = int(np.prod(shape)) * (4 if dtype == "f4" else 1)
+        self.own_bytes = self.nbytes if own_bytes is None else int(own_bytes)
+        if self.own_bytes != self.nbytes and (self.rank != 0 or transport == "torch"):
+            raise ValueError("only the root of the C-ABI transport may contribute less than a full slot")
+        if self.own_bytes != self.nbytes:
+            transport = "cabi"
         self.n = 0
         self.comm, self.transport_note = None, ""
         if self.on_cuda and transport in ("auto", "cabi"):
@@ -139,7 +177,7 @@ class FrameGather(object):
     def submit(self):
         s = self.n & 1
         if self.comm is not None:
-            self.comm.gather(self._src_ptr, self._flat[s].data_ptr() if self.rank == 0 else None, self.nbytes, 0)
+            self.comm.gather(self._src_ptr, self._flat[s].data_ptr() if self.rank == 0 else None, self.nbytes, 0, self.own_bytes)
         elif self.on_cuda:
             with self.torch.cuda.stream(self.stream):
                 # stream-level wait (not a host block): the COMPUTE stream must not refill this staging

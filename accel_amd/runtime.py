@@ -52,6 +52,7 @@ def _declare(lib):
         "accel_model_has_param": [vp, c.c_char_p],
         "accel_model_add_plan": [vp, c.c_char_p, c.c_char_p, c.POINTER(vp)],
         "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
+        "accel_plan_op_mode": [vp, c.c_int, c.POINTER(c.c_int)],
         "accel_tune_stats": [c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],
@@ -70,10 +71,12 @@ def _declare(lib):
         "accel_model_prefetch": [vp, c.c_char_p, vp, sz],
         "accel_model_commit": [vp, c.c_char_p],
         "accel_model_read_async": [vp, c.c_char_p, vp, sz],
+        "accel_comm_available": [],
         "accel_comm_unique_id": [vp],
         "accel_comm_create": [vp, i, i, vp, c.POINTER(vp)],
         "accel_comm_destroy": [vp],
         "accel_gather_logits": [vp, vp, vp, sz, i],
+        "accel_gather_frames": [vp, vp, sz, vp, sz, i],
         "accel_comm_sync": [vp],
         "accel_key_forward": [vp, vp, i, vp, vp, vp, i],
         "accel_cur_forward": [vp, vp, vp, i, vp, vp, vp, i],
@@ -285,6 +288,12 @@ class Comm(object):
     """RCCL communicator of the C ABI (accel_comm_*): one per process/GPU; `gather` is accel_gather_logits."""
 
     @staticmethod
+    def available():
+        """None if this process can resolve librccl and the entry points of the gather, else the reason (no communicator is made)"""
+        rc = lib().accel_comm_available()
+        return None if rc == 0 else lib().accel_last_error().decode()
+
+    @staticmethod
     def unique_id():
         buf = ctypes.create_string_buffer(128)
         check(lib().accel_comm_unique_id(buf))
@@ -296,9 +305,14 @@ class Comm(object):
         idb = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(lib().accel_comm_create(ctx.handle, self.rank, self.nranks, idb, ctypes.byref(self.handle)))
 
-    def gather(self, send_ptr, recv_ptr, nbytes, root=0):
-        check(lib().accel_gather_logits(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr) if recv_ptr else None,
-                                        int(nbytes), int(root)))
+    def gather(self, send_ptr, recv_ptr, nbytes, root=0, send_bytes=None):
+        """send_bytes < nbytes: a root that contributes fewer clips than the slot size (accel_gather_frames)"""
+        if send_bytes is None or int(send_bytes) == int(nbytes):
+            check(lib().accel_gather_logits(self.handle, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr) if recv_ptr else None,
+                                            int(nbytes), int(root)))
+        else:
+            check(lib().accel_gather_frames(self.handle, ctypes.c_void_p(send_ptr), int(send_bytes),
+                                            ctypes.c_void_p(recv_ptr) if recv_ptr else None, int(nbytes), int(root)))
 
     def sync(self):
         check(lib().accel_comm_sync(self.handle))
@@ -329,8 +343,10 @@ class Plan(object):
             check(lib().accel_plan_op_info(self.handle, i, kind, name, ctypes.byref(fl), ctypes.byref(by)))
             t, k, nw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             check(lib().accel_plan_op_launch(self.handle, i, ctypes.byref(t), ctypes.byref(k), ctypes.byref(nw)))
+            md = ctypes.c_int()
+            check(lib().accel_plan_op_mode(self.handle, i, ctypes.byref(md)))
             out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value,
-                        "tile": t.value, "ksplit": k.value, "narrow": nw.value})
+                        "tile": t.value, "ksplit": k.value, "narrow": nw.value, "mode": md.value})
         return out
 
     def run_serial(self):

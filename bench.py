@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--secondary", default="auto", choices=["auto", "none"],
                     help="auto: on a single GPU with the headline configuration also measure Accel-101, batch 1 and the "
                          "PCIe-inclusive loop (reported under `secondary`); none: headline only")
+    ap.add_argument("--root-relief", type=int, default=int(os.environ.get("ACCEL_BENCH_ROOT_RELIEF", "0")),
+                    help="N > 1 with --gather logits: rank 0 (which also receives every other rank's frames) processes this many clips "
+                         "fewer per call than the other ranks (dist.shard_clips(..., root_relief)); 0 = even shares")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, have each print its rank / world size, exit (no GPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -136,6 +139,114 @@ def main():
     finish()
 
 
+BF16_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0          # HBM3E spec; HBM_ACHIEVABLE_GBPS is the guide's measured float4-copy rate
+HBM_ACHIEVABLE_GBPS = 6300.0
+HBM_REGIME_GBPS = 3000.0        # a conv launch that moves its ALGORITHMIC bytes at >= 3 TB/s is priced against HBM, not the matrix pipe
+
+# executed matrix products per algorithmic multiply-add, dense peak of the pipe they run on, description
+PIPES = {"conv_igemm_b3_kernel": (6.0, BF16_PEAK_TFLOPS, "bf16 MFMA, six products per fp32 multiply-add (three exact bf16 terms per operand): conv_igemm_b3 / conv_b3r / conv_b3d kernels"),
+         "conv_wino_b3_kernel": (6.0 / 2.25, BF16_PEAK_TFLOPS, "bf16 MFMA, Winograd F(2x2,3x3) position GEMMs as six bf16 products each"),
+         "conv_wino_f32_kernel": (1.0 / 2.25, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA, Winograd F(2x2,3x3): 16/36 of the direct multiply-adds"),
+         "conv_igemm_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"), "conv_stem_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"),
+         "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (weight-stationary streaming 1x1)"),
+         "conv_f16_kernel": (1.0, BF16_PEAK_TFLOPS, "fp16 MFMA, ONE half product per multiply-add (f16-mode layer on any geometry: conv_igemm_f16 / conv_b3r<NPL=1> / conv_b3d<NPL=1>)")}
+
+
+def conv_family(op, dtype="f32"):
+    """Kernel family of one convolution launch.  `mode` (accel_plan_op_mode) is the arithmetic of the LAYER: an f16-mode layer
+    executes one half product per multiply-add on whichever geometry it was given (70-87 included), an fp32 layer on geometries
+    70-87 executes the six products of the three-term bf16 split."""
+    t, mode = op["tile"], op.get("mode", 1 if dtype == "f16" else 2 if dtype == "bf16x3" else 0)
+    if op.get("narrow"):
+        return "conv_narrow_kernel"
+    if mode == 1:
+        return "conv_f16_kernel"
+    if t in (41, 42, 43):
+        return "conv_wino_b3_kernel"
+    if t == 40:
+        return "conv_wino_f32_kernel"
+    if t == 50:
+        return "conv_stem_f32_kernel"
+    if t == 60:
+        return "conv1x1_ws_kernel"
+    if mode == 2 or 70 <= t <= 87:
+        return "conv_igemm_b3_kernel"
+    return "conv_igemm_f32_kernel"
+
+
+def roofline_from_launches(launches, dtype="f32"):
+    """launches: [(op dict of Plan.ops(), HIP-event duration in ms, launches per step)].
+
+    Every convolution launch is classed by REGIME first: one whose algorithmic bytes / duration reach HBM_REGIME_GBPS is bound by
+    HBM (the short-K 1x1 layers of res2 / res3 and the 64-channel layers) and is priced as bytes/s against the HBM roof; the rest
+    are priced against the matrix pipe their family EXECUTES on (PIPES: bf16x3 = 6 bf16 products per multiply-add at 2500 TFLOP/s,
+    Winograd 16/36 of the multiply-adds, fp16 mode ONE product).  The headline object is the deep-K (matrix-regime) class of the
+    dominant family; `hbm_class` is the same report for the HBM-regime launches; `all_conv.frac` = the share of the matrix-regime
+    convolution time an ideal pipe would need."""
+    fam, tot = {}, {"mfma": [0.0, 0.0, 0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0, 0.0, 0.0]}     # launches, ms, flops, bytes, ideal ms
+    fl = ms = n = by = clip_ms = 0.0
+    for op, d, wgt in launches:
+        clip_ms += wgt * d
+        if op["kind"] != "conv" or d <= 0:
+            continue
+        fl += wgt * op["flops"]; by += wgt * op["bytes"]; ms += wgt * d; n += wgt
+        name = conv_family(op, dtype)
+        regime = "hbm" if (op["bytes"] / (d * 1e-3) / 1e9 >= HBM_REGIME_GBPS or name not in PIPES) else "mfma"
+        f = fam.setdefault(name, {"mfma": [0.0, 0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0, 0.0]})[regime]
+        f[0] += wgt; f[1] += wgt * d; f[2] += wgt * op["flops"]; f[3] += wgt * op["bytes"]
+        t = tot[regime]
+        t[0] += wgt; t[1] += wgt * d; t[2] += wgt * op["flops"]; t[3] += wgt * op["bytes"]
+        if name in PIPES:
+            mul, pk, _ = PIPES[name]
+            t[4] += mul * wgt * op["flops"] / (pk * 1e12) * 1e3
+
+    def agg(v, name):
+        out = {"launches_per_step": int(v[0]), "ms_per_step": round(v[1], 3)}
+        if v[0]:
+            alg = v[2] / (v[1] * 1e-3) / 1e12
+            out.update({"avg_launch_us": round(1e3 * v[1] / v[0], 2), "algorithmic_tflops": round(alg, 2),
+                        "hbm_gbps_algorithmic": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                        "algorithmic_bytes_per_launch": round(v[3] / v[0]), "algorithmic_gflop_per_launch": round(v[2] / v[0] / 1e9, 3)})
+            if name in PIPES:
+                mul, pk, _ = PIPES[name]
+                out.update({"executed_tflops": round(mul * alg, 1), "executed_peak_tflops": pk, "executed_frac": round(mul * alg / pk, 4)})
+        return out
+    families = {}
+    for k, v in sorted(fam.items()):
+        both = [v["mfma"][i] + v["hbm"][i] for i in range(4)]
+        d = agg(both, k)
+        d["pipe"] = PIPES[k][2] if k in PIPES else "no matrix instructions (strip kernel for the 2-channel flow predictors): bandwidth / latency bound"
+        d["matrix_regime"] = agg(v["mfma"], k)
+        d["hbm_regime"] = agg(v["hbm"], k)
+        families[k] = d
+    dom = max((k for k in families if k in PIPES), key=lambda k: families[k]["matrix_regime"]["ms_per_step"])
+    D = families[dom]["matrix_regime"]
+    hb = tot["hbm"]
+    hbm_gbps = hb[3] / (hb[1] * 1e-3) / 1e9 if hb[1] else 0.0
+    mf = tot["mfma"]
+    return {"bound": "mfma", "kernel": dom, "achieved": D.get("executed_tflops"), "peak": D.get("executed_peak_tflops"), "unit": "TFLOP/s",
+            "frac": D.get("executed_frac"), "traffic": None, "traffic_note": None,
+            "achieved_note": "the DEEP-K (matrix-regime) launches of the dominant convolution family (%s: %.1f of %.1f ms of convolution time per step): "
+                             "EXECUTED flops (algorithmic 2 x MAC x the products its geometry executes per multiply-add) / the sum of their HIP-event "
+                             "durations, against the dense peak of the pipe it runs on (%s); launches that move their algorithmic bytes at >= %.0f GB/s "
+                             "are reported under hbm_class instead" % (dom, D["ms_per_step"], ms, PIPES[dom][2], HBM_REGIME_GBPS),
+            "avg_launch_us": D.get("avg_launch_us"), "launches_per_step": D["launches_per_step"],
+            "algorithmic_tflops": D.get("algorithmic_tflops"), "algorithmic_bytes_per_launch": D.get("algorithmic_bytes_per_launch"),
+            "algorithmic_gflop_per_launch": D.get("algorithmic_gflop_per_launch"),
+            "hbm_class": {"bound": "hbm", "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                          "frac_of_achievable": round(hbm_gbps / HBM_ACHIEVABLE_GBPS, 4), "launches_per_step": int(hb[0]), "ms_per_step": round(hb[1], 3),
+                          "what": "convolution launches whose algorithmic bytes (input + weights + residual + output, once each) / duration reach %.0f GB/s: "
+                                  "priced as bytes/s against HBM (8 TB/s spec, %.1f TB/s achievable per MI355X_MICROARCH.md)" % (HBM_REGIME_GBPS, HBM_ACHIEVABLE_GBPS / 1e3)},
+            "all_conv": {"frac": round(mf[4] / mf[1], 4) if mf[1] else None,
+                         "what": "time-weighted over every MATRIX-regime convolution launch of a step: sum(executed flop_i / peak_i) / sum(t_i)",
+                         "matrix_regime_ms_per_step": round(mf[1], 3), "hbm_regime_ms_per_step": round(hb[1], 3),
+                         "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms else None, "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2) if n else None,
+                         "gflop_per_launch": round(fl / n / 1e9, 3) if n else None, "algorithmic_bytes_per_launch": round(by / n) if n else None,
+                         "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)},
+            "families": families}
+
+
 class Workload(object):
     """Accel-<version> on this GPU, B clips per call, the clips (interval frames each) resident in HBM."""
 
@@ -159,13 +270,16 @@ class Workload(object):
         self.dev_frames = [torch.from_numpy(f).cuda() for f in self.host_frames]
         self.nbytes = B * 3 * H * W * 4
         self.gather = None
+        self.bind_inputs = os.environ.get("ACCEL_BENCH_BIND_INPUTS") == "1"
 
     def step(self):
         """one clip per lane: key frame + (interval - 1) non-key frames, inputs and outputs in HBM"""
         m = self.model
-        # the frames are resident in HBM: the plans read them where they lie (accel_model_bind_device), as an executor whose
-        # bound input already lives on the device does; ACCEL_BENCH_COPY_INPUTS=1 copies them into the model's input buffers
-        put = m.write_device if os.environ.get("ACCEL_BENCH_COPY_INPUTS") == "1" else m.bind_device
+        # the frames are resident in HBM and are COPIED into the model's input buffers every frame, as the reference's executor does
+        # with a source array on the device (executor_group._load_general: d_src.copyto(d_targets), unconditionally); the headline
+        # includes those copies.  ACCEL_BENCH_BIND_INPUTS=1: the plans read the frames where they lie (accel_model_bind_device) --
+        # reported as secondary.*_zero_copy_inputs, never as the headline
+        put = m.bind_device if self.bind_inputs else m.write_device
         for t in range(self.interval):
             put("data", self.dev_frames[t].data_ptr(), self.nbytes)
             if t == 0:
@@ -193,6 +307,7 @@ class Workload(object):
         for _ in range(steps):
             self.step()
         self.sync()
+        self.own_elapsed = time.perf_counter() - t0      # this rank's own work, before it waits for the others
         if dist is not None:
             dist.barrier()
         self.sync()
@@ -228,68 +343,12 @@ class Workload(object):
 
     def conv_roofline(self, dtype):
         """Roofline of the convolution kernels: a HIP-event pair around every launch on the compute stream
-        (accel_plan_profile), all conv launches of one step (1 key + interval-1 non-key plans).
-
-        Every family is priced against the pipe it EXECUTES on: the bf16x3 geometries run six bf16 MFMA products per
-        algorithmic multiply-add (executed = 6 x algorithmic, peak 2500 TFLOP/s dense bf16); Winograd F(2x2,3x3) executes
-        16/36 of the direct convolution's multiply-adds on the fp32 MFMA (executed = algorithmic / 2.25, peak 157.3); the
-        fp32 implicit GEMM, the 7x7 stem and the weight-stationary 1x1 kernel execute what they are asked (peak 157.3);
-        the narrow-N strip kernel has no matrix instructions (an HBM / L2 mover, left out of the matrix aggregate).
-        `frac` of the headline object = the DOMINANT family's executed rate / its peak; `all_conv.frac` = the time-weighted
-        aggregate sum(executed_i / peak_i) / sum(t_i) -- the share of the convolution time an ideal pipe would need."""
+        (accel_plan_profile), all conv launches of one step (1 key + interval-1 non-key plans); see roofline_from_launches."""
         kms, cms = self.key.profile(2), self.cur.profile(2)
-        fl = ms = n = by = 0.0
-        fam = {}
+        launches = []
         for plan, t, wgt in ((self.key, kms, 1), (self.cur, cms, self.interval - 1)):
-            for op, d in zip(plan.ops(), t):
-                if op["kind"] == "conv":
-                    fl += wgt * op["flops"]
-                    by += wgt * op["bytes"]
-                    ms += wgt * float(d)
-                    n += wgt
-                    name = ("conv_narrow_kernel" if op["narrow"] else "conv_wino_b3_kernel" if op["tile"] in (41, 42, 43) else "conv_wino_f32_kernel" if op["tile"] == 40
-                            else "conv_stem_f32_kernel" if op["tile"] == 50 else "conv1x1_ws_kernel" if op["tile"] == 60 else "conv_igemm_b3_kernel" if ((dtype == "bf16x3" and op["tile"] < 40) or 70 <= op["tile"] <= 81) else "conv_igemm_f16_kernel" if dtype == "f16" else "conv_igemm_f32_kernel")
-                    f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
-                    f[0] += wgt; f[1] += wgt * float(d); f[2] += wgt * op["flops"]; f[3] += wgt * op["bytes"]
-        clip_ms = float(kms.sum()) + (self.interval - 1) * float(cms.sum())
-        # executed multiply-adds per algorithmic one, and the dense peak of the pipe they run on (MI355X_MICROARCH.md)
-        pipe = {"conv_igemm_b3_kernel": (6.0, 2500.0, "bf16 MFMA, six products per fp32 multiply-add (three exact bf16 terms per operand)"),
-                "conv_wino_b3_kernel": (6.0 / 2.25, 2500.0, "bf16 MFMA, Winograd F(2x2,3x3) position GEMMs as six bf16 products each"),
-                "conv_wino_f32_kernel": (1.0 / 2.25, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA, Winograd F(2x2,3x3): 16/36 of the direct multiply-adds"),
-                "conv_igemm_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"), "conv_stem_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"),
-                "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (the layers it takes are HBM-side: see hbm_gbps)"),
-                "conv_igemm_f16_kernel": (1.0, 2500.0, "fp16 MFMA")}
-        families, ideal_ms, matrix_ms = {}, 0.0, 0.0
-        for k, v in sorted(fam.items()):
-            alg = v[2] / (v[1] * 1e-3) / 1e12 if v[1] else 0.0
-            d = {"launches_per_step": int(v[0]), "avg_launch_us": round(1e3 * v[1] / v[0], 2), "ms_per_step": round(v[1], 3),
-                 "algorithmic_tflops": round(alg, 2), "hbm_gbps_algorithmic": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[1] else 0.0,
-                 "algorithmic_bytes_per_launch": round(v[3] / v[0]), "algorithmic_gflop_per_launch": round(v[2] / v[0] / 1e9, 3)}
-            if k in pipe:
-                mul, pk, what = pipe[k]
-                d.update({"executed_tflops": round(mul * alg, 1), "executed_peak_tflops": pk, "executed_frac": round(mul * alg / pk, 4), "pipe": what})
-                ideal_ms += v[1] * mul * alg / pk
-                matrix_ms += v[1]
-            else:
-                d["pipe"] = "no matrix instructions (strip kernel for the 2-channel flow predictors): bandwidth / latency bound"
-            families[k] = d
-        dom = max((k for k in families if k in pipe), key=lambda k: families[k]["ms_per_step"])
-        D = families[dom]
-        return {"bound": "mfma", "kernel": dom, "achieved": D["executed_tflops"], "peak": D["executed_peak_tflops"], "unit": "TFLOP/s",
-                "frac": D["executed_frac"], "traffic": None, "traffic_note": None,
-                "achieved_note": "the dominant convolution family (%s: %.1f of %.1f ms of convolution time per step): EXECUTED flops "
-                                 "(algorithmic 2 x MAC of its launches x the products its geometry executes per multiply-add) / the sum of "
-                                 "their HIP-event durations, against the dense peak of the pipe it runs on (%s)"
-                                 % (dom, D["ms_per_step"], ms, D["pipe"]),
-                "avg_launch_us": D["avg_launch_us"], "launches_per_step": D["launches_per_step"],
-                "algorithmic_tflops": D["algorithmic_tflops"], "algorithmic_bytes_per_launch": D["algorithmic_bytes_per_launch"],
-                "algorithmic_gflop_per_launch": D["algorithmic_gflop_per_launch"],
-                "all_conv": {"frac": round(ideal_ms / matrix_ms, 4) if matrix_ms else None,
-                             "what": "time-weighted over every matrix-core convolution launch of a step: sum(executed flop_i / peak_i) / sum(t_i)",
-                             "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "launches_per_step": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
-                             "gflop_per_launch": round(fl / n / 1e9, 3), "algorithmic_bytes_per_launch": round(by / n),
-                             "conv_ms_per_step": round(ms, 3), "all_kernels_ms_per_step": round(clip_ms, 3)},
-                "families": families}
+            launches += [(op, float(d), wgt) for op, d in zip(plan.ops(), t)]
+        return roofline_from_launches(launches, dtype)
 
     def close(self):
         if self.gather is not None:
@@ -317,6 +376,61 @@ def _pmc_traffic(version, H, W, interval, dtype, B):
     return (round(d["read_bytes_per_launch"] + d["write_bytes_per_launch"]),
             "HBM read + write bytes per launch of %s from the committed PMC passes (%s): %s"
             % (" / ".join(d.get("kernels", ["the convolution kernels"])), os.path.relpath(files[-1], HERE), tr["method"]))
+
+
+def _gather_self_secondary(wl, a, B, H, W, local_rank, steps, warm, rate):
+    """What the collective costs the COMPUTE it runs beside, measured on the one GPU a bench box has: the headline loop with a
+    world-of-one RCCL communicator whose root block travels through ncclSend / ncclRecv to itself (ACCEL_GATHER_SELF_SENDRECV=1),
+    i.e. RCCL kernels moving the full per-call payload on the communication queue beside the next frame's kernels.  The link itself
+    (one xGMI hop per peer) is not exercised: DESIGN.md 6 combines these rates with the per-link limit."""
+    out = {}
+    import torch
+    import torch.distributed as dist
+    from accel_amd import dist as adist
+    made = False
+    saved = os.environ.get("ACCEL_GATHER_SELF_SENDRECV")
+    try:
+        if not dist.is_initialized():
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            made = True
+        os.environ["ACCEL_GATHER_SELF_SENDRECV"] = "1"
+        for what, shape, dt, per_frame in (("logits", (B, 19, H, W), "f4", 19 * H * W * 4), ("labels", (B, H, W), "u1", H * W)):
+            name = "accel18_batch%d_gather_self_%s" % (B, what)
+            try:
+                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, what, shape, dt, local_rank, transport="cabi")
+                el = wl.timed(steps, warm)
+                v = rate(wl, el, steps)
+                out[name] = {"value": v, "unit": "frames/s", "payload_bytes_per_call": per_frame * B,
+                             "peer_link_gbps_at_this_rate": round(per_frame * v / 1e9, 2),
+                             "what": "headline loop + per-frame gather of %s through ncclSend / ncclRecv to self on the communication stream "
+                                     "(compute-side cost of the collective; peer_link_gbps_at_this_rate = what ONE peer's xGMI link to the root "
+                                     "would have to carry at this frame rate)" % what}
+            except Exception as e:
+                out[name] = {"error": repr(e)}
+            finally:
+                if wl.gather is not None:
+                    try:
+                        wl.sync()
+                        wl.gather.close()
+                    except Exception:
+                        pass
+                wl.gather = None
+    except Exception as e:
+        out["accel18_batch%d_gather_self_logits" % B] = {"error": repr(e)}
+    finally:
+        if saved is None:
+            os.environ.pop("ACCEL_GATHER_SELF_SENDRECV", None)
+        else:
+            os.environ["ACCEL_GATHER_SELF_SENDRECV"] = saved
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    return out
 
 
 def _run(a):
@@ -348,13 +462,17 @@ def _run(a):
     update_config(os.path.join(HERE, "tests", "golden", "dff_deeplab_vid_demo.yaml"))
     config.SCALES[0] = (H, W)
 
-    wl = Workload(a.version, B, H, W, a.interval, local_rank, rank, config)
+    # the root of the logits gather also receives every other rank's frames: --root-relief gives it that many clips fewer per call
+    relief = min(max(0, a.root_relief), B - 1) if (world > 1 and a.gather == "logits") else 0
+    B_rank = B - relief if rank == 0 else B
+    wl = Workload(a.version, B_rank, H, W, a.interval, local_rank, rank, config)
 
     gather_note = "none (single GPU)"
     if (world > 1 or force_dist) and a.gather != "none":
         try:
             if a.gather == "logits":
-                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank)
+                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank,
+                                              own_bytes=B_rank * 19 * H * W * 4 if B_rank != B else None)
             else:
                 wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank)
             gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered, transport %s%s" % (
@@ -378,7 +496,14 @@ def _run(a):
     wl.step = guarded_step
 
     elapsed = wl.timed(a.steps, a.warmup, dist)
+    rank_ms = None
     if dist is not None:
+        # every rank's own time for the K steps (between the two barriers a rank that finishes early waits in the second one, so
+        # its own clock is stopped before that barrier): a straggling root shows here
+        own = torch.tensor([wl.own_elapsed], dtype=torch.float64, device="cuda")
+        alls = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(alls, own)
+        rank_ms = [round(1e3 * float(x.item()) / a.steps, 3) for x in alls]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -391,14 +516,15 @@ def _run(a):
         try:
             wl.sync()
             wl.gather.close()
-            wl.gather = (adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank) if other == "labels"
+            wl.gather = (adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank,
+                                           own_bytes=B_rank * H * W if B_rank != B else None) if other == "labels"
                          else adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank))
             el2 = wl.timed(a.steps, 1, dist)
             t2 = torch.tensor([el2], dtype=torch.float64, device="cuda")
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             el2 = float(t2.item())
             per_frame = {"logits": 19 * H * W * 4, "labels": H * W}
-            fps = lambda el: world * a.steps * a.interval * B / el
+            fps = lambda el: (world * B - relief) * a.steps * a.interval / el
             gather_detail = {
                 "gather_" + a.gather: {"value": round(fps(elapsed), 2), "unit": "frames/s",
                                        "peer_link_gbps": round(per_frame[a.gather] * fps(elapsed) / world / 1e9, 2)},
@@ -412,7 +538,7 @@ def _run(a):
     headline_cfg = a.version == "18" and (H, W) == (1024, 2048) and a.interval == 5 and a.dtype == "f32"
     out = None
     if rank == 0:
-        frames_total = world * a.steps * a.interval * B
+        frames_total = (world * B - relief) * a.steps * a.interval
         value = frames_total / elapsed
         out = {"metric": "frames/sec 1024x2048 Accel-%s kf=%d" % (a.version, a.interval), "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -435,13 +561,19 @@ def _run(a):
                                       "%dx%d clips, key-frame interval %d, %d clip(s) (1 key + %d non-key frames each) per GPU per step, "
                                       "processed %d clips at a time (batched frames of independent clips)"
                                       % (a.version, a.version, H, W, a.interval, B, a.interval - 1, B),
-                          "frames_per_step_per_gpu": a.interval * B, "clips_per_call": B, "parallelism": "clip-sharded x%d (weights replicated)" % world,
+                          "frames_per_step_per_gpu": a.interval * B, "clips_per_call": B, "root_relief_clips": relief,
+                          "inputs": ("frames resident in HBM, COPIED into the model's input buffers every frame (the reference executor's "
+                                     "_load_general copy; device to device)" if not wl.bind_inputs else
+                                     "frames resident in HBM, read where they lie (ACCEL_BENCH_BIND_INPUTS=1: zero-copy, not the reference's semantics)"),
+                          "parallelism": "clip-sharded x%d (weights replicated)" % world,
                           "gather": gather_note + ("; DISABLED after failure: " + gather_failures[0] if gather_failures else ""), "weights": "seeded random",
                           "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
                                        "taken from the warped W_fc6*feat image of the key frame" if os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
                                        else "reference layer list one to one (ACCEL_FOLD_LINEAR=0)"), "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
     if rank == 0 and gather_detail is not None:
         out["gather_rates"] = gather_detail
+    if rank == 0 and rank_ms is not None:
+        out["rank_ms_per_step"] = rank_ms
     if rank == 0 and not a.no_roofline:
         out["roofline"] = wl.conv_roofline(a.dtype)
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = _pmc_traffic(a.version, H, W, a.interval, a.dtype, B)
@@ -453,6 +585,18 @@ def _run(a):
 
         def rate(w, el, steps):
             return round(steps * a.interval * w.B / el, 2)
+        try:        # the headline loop with the frames read where they lie instead of copied (accel_model_bind_device)
+            wl.bind_inputs = True
+            el = wl.timed(steps2, warm2)
+            sec["accel18_batch%d_zero_copy_inputs" % B] = {
+                "value": rate(wl, el, steps2), "unit": "frames/s",
+                "what": "the headline workload with the resident frames bound (zero-copy) instead of copied into the model's input buffers: "
+                        "9 device-to-device copies of %d MB per step less; an extension, not the reference executor's semantics" % (wl.nbytes >> 20)}
+        except Exception as e:
+            sec["accel18_batch%d_zero_copy_inputs" % B] = {"error": repr(e)}
+        finally:
+            wl.bind_inputs = os.environ.get("ACCEL_BENCH_BIND_INPUTS") == "1"
+        sec.update(_gather_self_secondary(wl, a, B, H, W, local_rank, steps2, warm2, rate))
         try:
             el = wl.timed_pcie(steps2, warm2)
             sec["accel18_batch%d_pcie_inclusive" % B] = {

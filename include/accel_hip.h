@@ -84,6 +84,10 @@ int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double*
 /* launch decisions of op i after finalize (autotuned or heuristic): conv tile id (conv_igemm.hip, -1 for
  * non-conv ops), split-K factor, 1 if the narrow-N kernel runs it.  Diagnostic only. */
 int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narrow);
+/* arithmetic mode of conv op i: 0 = fp32 layer (its launch geometry may still execute on the bf16 matrix cores as an exact
+ * three-term split: tile 70-87), 1 = fp16-MFMA layer (plan option dtype=f16: ONE half product per multiply-add whatever the
+ * geometry), 2 = bf16x3 layer (plan option dtype=bf16x3); -1 for non-conv ops.  Diagnostic only (bench.py prices families by it). */
+int accel_plan_op_mode(accel_plan* p, int i, int* mode);
 /* Launch geometries are REPRODUCIBLE: decisions come from the table shipped beside the library (tune/gfx950.tune, covers
  * the BASELINE workloads) or from the user's table ($ACCEL_TUNE_CACHE, else ~/.cache/accel_amd/gfx950.tune); a shape in
  * neither is timed once and appended to the user's table.  Counters of this process: decisions replayed, decisions
@@ -109,9 +113,13 @@ int accel_model_read(accel_model* m, const char* buf, void* dst, size_t bytes, i
 /* Zero-copy input: the image input `buf` (`data`, `data_key` -- a buffer that only the input-conversion kernels of the
  * finalized plans read) is read from the caller's device buffer `devptr` (`bytes` = the size of `buf`, same layout) by every
  * plan run that follows, until the next accel_model_write / accel_model_commit into `buf` or the next bind.  Stream-ordered
- * on the context stream like a write; the caller keeps `devptr` alive and unchanged until those runs have completed.  This is
- * what an MXNet executor does when the bound input NDArray already lives on the device (executor_group.py:18-27 copies only
- * when source and destination differ); bench.py uses it for frames that are resident in HBM. */
+ * on the context stream like a write; the caller keeps `devptr` alive and unchanged until those runs have completed.
+ * An EXTENSION, not the reference's behaviour: DataParallelExecutorGroup._load_general (executor_group.py:18-27) ALWAYS copies
+ * the source array into the executor's bound input (d_src.copyto(d_targets)), also when the source already lives on the
+ * device -- accel_model_write(src_on_device = 1) is that copy, and bench.py's headline uses it; the zero-copy binding is
+ * reported separately (secondary.*_zero_copy_inputs).  accel_model_buffer(buf) and accel_model_read(buf) of a bound buffer:
+ * a raw pointer hand-out ends the binding (the caller is about to write the model's own copy), a read returns the bytes the
+ * plans would read (the bound frame). */
 int accel_model_bind_device(accel_model* m, const char* buf, const void* devptr, size_t bytes);
 int accel_model_buffer(accel_model* m, const char* buf, void** dev_ptr, size_t* bytes);
 /* Write generation of a persistent buffer: starts at 0, bumped by every accel_plan_run of a plan that writes the
@@ -193,6 +201,10 @@ int accel_flow_input(accel_ctx* ctx, const float* cur, const float* prev, int H,
  * (dff_rfcn/function/test_rcnn.py:62-82, dff_rfcn/core/tester.py:290-298: one thread per GPU, results appended on the
  * host).  One process per GPU; RCCL (librccl, resolved at run time) point-to-point send/recv over xGMI: every peer
  * uses its own direct link to the root, no ring.
+ *   accel_comm_available   0 if THIS process can resolve librccl and every entry point the gather uses (no communicator, no
+ *                          network activity); else an error whose text says what is missing.  Every rank calls it and the
+ *                          ranks agree on the outcome BEFORE any of them enters accel_comm_create (ncclCommInitRank blocks
+ *                          until all ranks have arrived: a rank that cannot load the library must not leave the others there)
  *   accel_comm_unique_id   128-byte id, made on one rank and distributed by the caller (file, socket, torch.distributed)
  *   accel_comm_create      communicator of `nranks` processes, this one being `rank`, bound to ctx's device; owns a
  *                          communication stream and two staging slots
@@ -203,10 +215,14 @@ int accel_flow_input(accel_ctx* ctx, const float* cur, const float* prev, int H,
  *                          stay untouched until accel_comm_sync() or the second-next gather.
  *   accel_comm_sync        host wait for all gathers issued so far */
 typedef struct accel_comm accel_comm;
+int accel_comm_available(void);
 int accel_comm_unique_id(void* id128);
 int accel_comm_create(accel_ctx* ctx, int rank, int nranks, const void* id128, accel_comm** out);
 int accel_comm_destroy(accel_comm* comm);
 int accel_gather_logits(accel_comm* comm, const void* sendbuf, void* recvbuf_or_null, size_t bytes, int root);
+/* the same with a ROOT that contributes fewer bytes than a full slot (`bytes` = slot size = what every peer sends; the root, which
+ * also receives all the others' frames, may be given fewer clips: send_bytes <= bytes on the root, == bytes elsewhere) */
+int accel_gather_frames(accel_comm* comm, const void* sendbuf, size_t send_bytes, void* recvbuf_or_null, size_t bytes, int root);
 int accel_comm_sync(accel_comm* comm);
 
 #ifdef __cplusplus

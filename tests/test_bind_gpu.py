@@ -49,6 +49,18 @@ def test_bound_frames_give_the_same_logits_as_copied_frames(demo_cfg, monkeypatc
         k2 = wl.model.read("logits", (wl.B, 19, H, W)).copy()
         wl.dev_frames[0].copy_(keep)
         assert np.array_equal(k0, a[0]) and not np.array_equal(k2, k0)
+        # a read of a bound input returns what the plans read (the caller's frame), not the model-owned copy left by an earlier write
+        wl.model.write_device("data", wl.dev_frames[1].data_ptr(), wl.nbytes)
+        wl.model.bind_device("data", wl.dev_frames[2].data_ptr(), wl.nbytes)
+        assert np.array_equal(wl.model.read("data", (wl.B, 3, H, W)), wl.dev_frames[2].cpu().numpy())
+        # a raw-pointer hand-out ends the binding: what the caller then writes through the pointer is what the plans read
+        # (the Predictor path does exactly this: tester.py takes m.buffer('data_key') and copies the previous frame into it)
+        ptr, nb = wl.model.buffer("data")
+        assert nb == wl.nbytes
+        torch_dst = __import__("accel_amd.dist", fromlist=["as_torch"]).as_torch(ptr, (wl.B, 3, H, W))
+        torch_dst.copy_(wl.dev_frames[0])
+        wl.key.run()
+        assert np.array_equal(wl.model.read("logits", (wl.B, 19, H, W)), a[0]), "a write through accel_model_buffer's pointer was ignored"
         with pytest.raises(AccelError, match="not an image input"):
             wl.model.bind_device("feat", wl.dev_frames[0].data_ptr(), wl.nbytes)
         with pytest.raises(AccelError, match="bytes"):

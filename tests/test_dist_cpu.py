@@ -13,6 +13,14 @@ import torch.multiprocessing as mp
 from accel_amd import dist as adist
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_shard_clips_partitions_exactly():
     for n, w in [(64, 8), (10, 4), (3, 8), (0, 2), (7, 1)]:
         parts = [adist.shard_clips(n, w, r) for r in range(w)]
@@ -20,6 +28,61 @@ def test_shard_clips_partitions_exactly():
         assert flat == list(range(n))                       # disjoint, ordered, complete
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= (n + w - 1) // w
     assert adist.shard_clips(64, 8, 3) == list(range(24, 32))   # config 4: 8 contiguous clips per GPU
+
+
+def test_shard_clips_with_a_relieved_root():
+    """the root of the logits gather also receives every other rank's frames: root_relief takes clips off rank 0 and hands them to
+    the least loaded peers; the partition stays contiguous, disjoint and complete"""
+    for n, w, r in [(64, 8, 1), (64, 8, 2), (10, 4, 1), (3, 8, 1), (16, 2, 3), (7, 1, 2), (0, 4, 1)]:
+        parts = [adist.shard_clips(n, w, k, root_relief=r) for k in range(w)]
+        assert [c for p in parts for c in p] == list(range(n)), (n, w, r)
+        even = [len(adist.shard_clips(n, w, k)) for k in range(w)]
+        if w > 1:
+            base0 = n // w + (1 if n % w else 0)
+            assert len(parts[0]) == max(0, base0 - r) and len(parts[0]) <= even[0]
+            assert sum(len(p) for p in parts[1:]) == n - len(parts[0])
+            assert max(len(p) for p in parts[1:]) - min(len(p) for p in parts[1:]) <= 1 + (1 if n % w else 0)
+    assert [len(adist.shard_clips(64, 8, k, root_relief=1)) for k in range(8)] == [7, 8, 8, 8, 8, 8, 8, 9]
+    assert [len(adist.shard_clips(64, 8, k, root_relief=0)) for k in range(8)] == [8] * 8
+    assert adist.shard_clips(7, 1, 0, root_relief=2) == list(range(7))          # nobody to relieve
+
+
+def _comm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if rank == 1:
+        os.environ["ACCEL_RCCL_UNAVAILABLE"] = "1"       # this rank behaves as if librccl could not be loaded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from accel_amd import runtime
+
+        class Ctx(object):
+            device_id = 0
+        try:
+            adist.make_comm(Ctx())
+            q.put((rank, "created"))
+        except runtime.AccelError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_no_rank_enters_the_communicator_init_when_one_rank_cannot_load_rccl():
+    """ncclCommInitRank blocks until every rank has arrived, so a rank that cannot resolve librccl must be found out BEFORE anybody
+    calls it: every rank probes (accel_comm_available) and the ranks vote first.  Rank 1 is made unable here; both ranks must come
+    back with AccelError (and FrameGather would fall back to torch.distributed on both) instead of rank 0 hanging in the init."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "ACCEL_RCCL_UNAVAILABLE" in res[1] and "rank 1" in res[1]
+    assert "another rank cannot resolve librccl" in res[0] or "librccl" in res[0]
+    assert "created" not in res.values()
 
 
 def test_greedy_video_assignment_matches_reference_rule():
@@ -41,14 +104,6 @@ class _FakeModel(object):
 
     def read(self, name, shape, dtype):
         return self.cur.reshape(shape).astype(dtype)
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _worker(rank, world, port, q):
