@@ -20,6 +20,7 @@ with a golden fixture.  The distributions keep activations O(1) through the
        pixel value at h = 0): any rounding difference then flips isolated feature pixels by several units, see
        DESIGN.md "numerics".  Large offsets stay covered by the operator-level stress tests.)
   FlowNet flow predictors scaled so |flow| is a few feature pixels
+  Accel-101 corr_weight (2048 x 4096 feature fusion): 0.5 [I | I] + 0.25 x He noise, so that non-key frames keep several classes
 """
 import zlib
 
@@ -61,6 +62,14 @@ def make_param(name, shape, offset_std=0.0016, flow_gain=1.0, salt=0):
         return r.uniform(0.5, 1.5, shape).astype(np.float32)
     if name.endswith("_bias"):
         return r.normal(0, 0.01, shape).astype(np.float32)
+    if name == "corr_weight" and len(shape) == 4 and shape[0] >= 1024 and shape[1] == 2 * shape[0] and shape[2:] == (1, 1):
+        # Accel-101's feature fusion (accel_101.py:171-176: 1x1 conv over concat(warped key feature, current feature), 4096 -> 2048):
+        # an averaging fusion 0.5 [I | I] plus a quarter of the He noise.  A pure He draw gives every fused channel a DC term
+        # (4096 all-positive inputs) that swamps the spatial signal, and the non-key label map of the seeded model is then ONE
+        # class at every pixel -- "labels identical" would prove nothing there (round-3 review); with this rule the non-key
+        # frames carry 5-6 classes like the key frame.
+        eye = np.concatenate([np.eye(shape[0]), np.eye(shape[0])], axis=1).reshape(shape)
+        return (0.5 * eye + 0.25 * r.normal(0, np.sqrt(2.0 / shape[1]), shape)).astype(np.float32)
     if name.endswith("_weight"):
         if "_offset_" in name:
             return r.normal(0, offset_std, shape).astype(np.float32)

@@ -1,8 +1,8 @@
 """Shared parity check of whole-clip runs against the CPU oracle, with the label-margin histogram SURVEY.md 7
 ("hard parts") asks for.
 
-Logits: |hip - oracle| <= max(1e-3, 1e-5 * max|oracle|)   (BASELINE.json north star: "logits within 1e-3 fp32"; logits
-of +-110 have an fp32 ulp of 7.6e-6, hence the second term) -- everywhere, except inside at most two 64x64 windows per
+Logits: |hip - oracle| <= 1e-3, absolute and flat (BASELINE.json north star: "logits within 1e-3 fp32") -- everywhere, except
+inside at most two 64x64 windows per
 frame that are each VERIFIED to sit at a deformable-convolution border discontinuity the oracle itself recorded.
 Labels: with e = the MEASURED max logit error of the frame, a label can legitimately differ from the oracle's only
 where the oracle's top-2 margin is <= 2e (top-1 down by e, runner-up up by e).  So labels must be IDENTICAL wherever
@@ -70,13 +70,15 @@ def flip_windows(err_map, tol, win=64, max_windows=2, critical=None, radius=RADI
     return mask, centres
 
 
-def logit_tolerance(ref_logits, abs_tol=1e-3, rel_tol=1e-5):
-    """BASELINE.json north star: "logits within 1e-3 fp32" -- absolute; on logits beyond +-100 (the synthetic weights reach
-    +-110) one fp32 ulp of the value is 7.6e-6, so the bound is 1e-3 or 1e-5 of the largest logit, whichever is larger."""
+def logit_tolerance(ref_logits, abs_tol=1e-3, rel_tol=0.0):
+    """BASELINE.json north star: "logits within 1e-3 fp32" -- absolute, flat, whatever the size of the logits (the synthetic
+    weights reach +-130; rounds 2-3 added 1e-5 of the largest logit, which the measured errors never needed: 3.4e-4 ... 4.9e-4
+    at 1024x2048, 8.4e-4 on the x20 offset stress clip).  rel_tol stays as a parameter for comparisons that are not parity
+    claims (two HIP evaluations of a reduced-precision mode)."""
     return max(abs_tol, rel_tol * float(np.abs(ref_logits).max()))
 
 
-def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=1e-5, max_mismatch=1e-3, max_windows=2):
+def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=0.0, max_mismatch=1e-3, max_windows=2, min_classes=2):
     lines = []
     crit_all = getattr(ref, "critical", None)
     for t, ((lg, lab), (rlg, rlab)) in enumerate(zip(outs, ref)):
@@ -95,9 +97,13 @@ def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=1e-5, max_mismatc
             lab = np.where(keep, np.asarray(lab).reshape(rlab.shape), rlab)
         err = float(np.abs(lg - rlg).max())
         lab = np.asarray(lab).reshape(rlab.shape)
+        # "labels identical" means something only if the label map is not one class everywhere (round 3: Accel-101's non-key map was)
+        assert len(np.unique(rlab)) >= min_classes and len(np.unique(lab)) >= min_classes, (
+            "%s frame %d: degenerate label map (%d class(es) in the oracle's, %d in the path's): the label comparison is vacuous"
+            % (tag, t, len(np.unique(rlab)), len(np.unique(lab))))
         margin, rows = margin_histogram(rlg, lab, rlab, err, tol)
-        lines.append("%s frame %d: max|logit err| e=%.3g (tol %.3g, |logit|max %.3g, %d border-tap points); pixels / label "
-                     "mismatches per oracle top-2 margin bin: %s" % (tag, t, err, tol, float(np.abs(rlg).max()), len(crit or []),
+        lines.append("%s frame %d: max|logit err| e=%.3g (tol %.3g, |logit|max %.3g, %d classes in the label map, %d border-tap points); pixels / label "
+                     "mismatches per oracle top-2 margin bin: %s" % (tag, t, err, tol, float(np.abs(rlg).max()), len(np.unique(rlab)), len(crit or []),
                                                                     "  ".join("%s %d/%d" % (n, c, m) for n, c, m in rows)))
         assert err <= tol, "%s frame %d: logits err %g > %g" % (tag, t, err, tol)
         safe = margin > 2 * err

@@ -81,7 +81,8 @@ def test_winograd_bf16_geometry_on_every_eligible_layer_vs_oracle(demo_cfg, monk
 def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkeypatch):
     """What bench.py times: one call = one frame of each of 8 independent clips at 1024x2048.  Image b of the batched
     call must reproduce the batch-1 run of clip b over a key and a non-key frame (tile choices differ between the two
-    binds, so sums may differ in the last bits: 1e-4 of the logit range; labels identical outside the tie band)."""
+    binds, so sums may differ in the last bits: 1e-4 of the logit range; labels identical outside the tie band); image 0 of the
+    batched call is also checked against the oracle's run of clip 0."""
     from accel_amd import demo, mx
     from accel_amd.core import tester
     H, W, B, interval = 1024, 2048, 8, 2
@@ -102,13 +103,14 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkey
                 single[b][t] = (lg.asnumpy()[0][:, ::2, ::2].copy(), np.uint8(lab.asnumpy()[0]))
         tester.release_models()
         rb = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W), batch=B)
-        carried = []
+        carried, image0 = [], []
         for t in range(interval):
             arrays = [mx.nd.array(np.concatenate([per_clip[b][t][i].asnumpy() for b in range(B)], axis=0)) for i in range(2)]
             arrays.append(mx.nd.array(np.zeros((B, 2048, 1, 1), np.float32)))
             logits, labels = rb.step(t, arrays, interval)
             lg, lab = logits.asnumpy(), labels.asnumpy()
             assert lg.shape == (B, 19, H, W) and lab.shape == (B, H, W)
+            image0.append((lg[0:1].copy(), lab[0:1].copy()))
             pred = rb.key_predictor if t % interval == 0 else rb.cur_predictor
             pts = hip_border_points(*pred.plan_for(H, W, B, slot=0))
             carried = pts if t % interval == 0 else carried + pts
@@ -125,6 +127,12 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkey
                 assert float((np.uint8(lab[b]) != rlab).mean()) < 2e-3, (t, b)
     finally:
         tester.release_models()
+    # ... and the batched call against the ORACLE directly: image 0 of the 8-clip call (the launch geometries bench.py replays:
+    # M = 8x the rows, other table entries than the one-clip bind) must meet the same bar as a one-clip run does
+    P = dict(arg)
+    P.update(aux)
+    ref = G.run_clip(P, "18", _oracle_frames(clips[0], demo_cfg), interval)
+    check_against_oracle(image0, ref, "config4 accel-18 1024x2048, image 0 of the 8-clip call")
 
 
 def test_config2_accel18_1024x2048_vs_oracle(demo_cfg, monkeypatch):
