@@ -154,21 +154,9 @@ class Predictor(object):
         # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
         # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
         pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
-        # ONE stream by default.  A two-stream lowering exists (the per-frame correction branch on a side stream beside
-        # FlowNet / warp / head: +2-5 % at one clip per call, nothing at 8 clips per call), but on this ROCm / gfx950 stack
-        # kernels of the side stream occasionally read 256-byte granules of data that an EARLIER kernel of the same stream
-        # produced as if they had not been written, while a bandwidth-heavy kernel of the other hardware queue is running
-        # (DESIGN.md 7 "two-stream hazard", scripts/debug/twostream_bisect.py: not a missing dependency of the plan, not a
-        # hipGraph effect, not a kernel of this library -- kernel order, arena layout, explicit L2 fences were all ruled
-        # out).  ACCEL_MULTI_STREAM=1 opts in and warns once.
+        # every plan is lowered for ONE stream (a two-stream lowering existed until round 3 and was removed: DESIGN.md 7)
         fold = os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
-        multi = os.environ.get("ACCEL_MULTI_STREAM", "0") == "1"
-        if multi and not getattr(Predictor, "_warned_multi", False):
-            import warnings
-            warnings.warn("ACCEL_MULTI_STREAM=1: two-stream plans can return wrong frames on this stack (DESIGN.md 7, "
-                          "two-stream hazard); results are not covered by the parity tests", RuntimeWarning)
-            Predictor._warned_multi = True
-        kw = dict(multi_stream=multi, conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"), fold_linear=fold)
+        kw = dict(conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"), fold_linear=fold)
         text, lw = _lower.lower(self._symbol, shapes, feat_slot=0 if pingpong else None, **kw)
         pingpong = pingpong and any(getattr(getattr(v, "buf", None), "space", None) == "feat_b" for v in lw.outputs.values())
         if not pingpong and lw.feat_slot is not None:

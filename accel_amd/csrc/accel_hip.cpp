@@ -58,7 +58,6 @@ extern "C" const char* accel_version(void) { return "accel_hip 0.1 (gfx950)"; }
 struct accel_ctx {
     int device;
     hipStream_t stream;     // compute stream (the one callers order against)
-    hipStream_t stream1;    // side stream for the independent branch of two-stream plans
     hipStream_t copy;       // host<->HBM prefetch stream (accel_model_prefetch)
 };
 
@@ -138,10 +137,6 @@ struct Op {
     const float* const* slot_b = nullptr;
     size_t nbytes = 0;
     int H = 0, W = 0;
-    int stream = 0;             // 0 = compute stream, 1 = side stream
-    std::vector<int> waits;     // op indices (on the other stream) this op depends on
-    bool signal = false;        // some op on the other stream waits for this one
-    hipEvent_t done = nullptr;
 };
 
 struct accel_plan {
@@ -157,11 +152,8 @@ struct accel_plan {
     bool allow_graph = true;
     bool allow_tune = true;
     int f16 = 0;                    // option dtype=f16: convolutions on the fp16 matrix cores; dtype=bf16x3: 2 (kernels.h)
-    size_t ws_bytes = 0;            // split-K workspace shared by the convs of one stream (stream-ordered)
+    size_t ws_bytes = 0;            // split-K workspace shared by the convs of the plan (stream-ordered)
     float* ws = nullptr;
-    float* ws1 = nullptr;
-    bool two_streams = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<std::string> pbuf_reads, pbuf_writes;   // persistent buffers the ops read / write (derived-buffer tracking)
 };
 
@@ -304,13 +296,8 @@ static int parse_plan(accel_plan* p, const char* text)
         op.kind_name = kind;
         op.kv = kv;
         op.name = kv_str(kv, "name");
-        op.stream = (int)kv_int(kv, "stream", 0);
-        if (op.stream) p->two_streams = true;
-        if (kv_has(kv, "wait")) {
-            std::stringstream ws_(kv_str(kv, "wait"));
-            std::string t;
-            while (std::getline(ws_, t, ',')) op.waits.push_back(atoi(t.c_str()));
-        }
+        if (kv_int(kv, "stream", 0) != 0 || kv_has(kv, "wait"))
+            return fail(ACCEL_ERR_PLAN, "op %s: plans run on one stream (the two-stream lowering was removed, DESIGN.md 7)", op.name.c_str());
         op.flops = kv_f(kv, "flops");
         op.bytes = kv_f(kv, "bytes");
         if (kind == "prep_rgb") op.kind = OP_PREP_RGB;
@@ -916,9 +903,9 @@ static int finalize_op(accel_plan* p, Op& op)
     return fail(ACCEL_ERR_PLAN, "unhandled op kind");
 }
 
-static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
+static int launch_op(accel_plan* p, Op& op)
 {
-    hipStream_t st = (op.stream == 1 && !single_stream) ? p->m->ctx->stream1 : p->m->ctx->stream;
+    hipStream_t st = p->m->ctx->stream;
     hipError_t e = hipSuccess;
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
@@ -967,26 +954,12 @@ static int launch_op(accel_plan* p, Op& op, bool single_stream = false)
     return 0;
 }
 
-// Issues the plan.  Two-stream plans fork the side stream from the compute stream, order the few
-// cross-stream reads with events, and join at the end -- under stream capture this becomes a graph
-// with two parallel branches, eagerly it is the same thing with real events.
+// Issues the plan: every op in list order on the context's compute stream (under stream capture this becomes a linear graph).
 static int run_eager(accel_plan* p)
 {
-    accel_ctx* c = p->m->ctx;
-    if (p->two_streams) {
-        HIP_TRY(hipEventRecord(p->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream1, p->ev_fork, 0));
-    }
     for (Op& op : p->ops) {
-        hipStream_t st = op.stream == 1 ? c->stream1 : c->stream;
-        for (int j : op.waits) HIP_TRY(hipStreamWaitEvent(st, p->ops[j].done, 0));
         int rc = launch_op(p, op);
         if (rc) return rc;
-        if (op.signal) HIP_TRY(hipEventRecord(op.done, st));
-    }
-    if (p->two_streams) {
-        HIP_TRY(hipEventRecord(p->ev_join, c->stream1));
-        HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_join, 0));
     }
     return 0;
 }
@@ -1169,9 +1142,16 @@ static int autotune_plan(accel_plan* p)
                 if (base) cs.push_back({t, 0, 1});
             }
         }
-        if (const char* fw = getenv("ACCEL_WB3_FORCE"); fw && c.wub && !c.f16) {      // diagnostics: every layer that can take 41 / 42, does
+        if (const char* fw = getenv("ACCEL_WB3_FORCE"); fw && c.wub && !c.f16) {
+            // diagnostics: every layer that can take 41 / 42 / 43, does.  The geometry goes straight into the layer's parameters:
+            // nothing is looked up in, inserted into or erased from the process-wide launch-geometry table (a forced run used to
+            // replace shipped decisions for the rest of the process, so later tests of the same session ran on geometry 43)
             cs.clear();
-            cs.push_back({atoi(fw), 0, 0});
+            conv_apply(op.conv, atoi(fw), 0, 0);
+            ConvParams q = op.conv;
+            const size_t w = conv_plan_split(q);
+            if (w > ws_need) ws_need = w;
+            continue;
         }
         for (const Cand& k : cs) { ConvParams q = c; size_t w = conv_apply(q, k.tile, k.split_target, k.no_split); if (w > ws_need) ws_need = w; }
     }
@@ -1180,9 +1160,8 @@ static int autotune_plan(accel_plan* p)
         HIP_TRY(hipMalloc((void**)&nw, ws_need));
         poison(nw, ws_need);
         p->owned.push_back(nw);
-        p->ws = p->ws1 = nw; p->ws_bytes = ws_need;
-        if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, ws_need)); p->owned.push_back(p->ws1); }
-        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
+        p->ws = nw; p->ws_bytes = ws_need;
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = p->ws;
     }
     struct TuneScratch {      // released on every way out of this function
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1219,7 +1198,9 @@ static int autotune_plan(accel_plan* p)
             // geometry the plan withholds from the layer, must not turn into an invalid launch): otherwise the layer is timed again
             bool known = false;
             for (const auto& k : cands[i]) known |= k.tile == it->second.tile;
-            if (!known) { g_tune_cache.erase(it); it = g_tune_cache.end(); }
+            // (a shipped entry that is timed again leaves the shipped set: tune_cache_save skips shipped keys, and the new decision
+            // must reach the user's table instead of being re-timed -- with another outcome, possibly -- in every process)
+            if (!known) { g_tune_shipped.erase(it->first); g_tune_cache.erase(it); it = g_tune_cache.end(); }
         }
         if (it == g_tune_cache.end()) {
             // Each candidate is timed the way the launch will run inside the plan: weights cold (L2 and the 256 MB
@@ -1234,7 +1215,7 @@ static int autotune_plan(accel_plan* p)
                 float ms_min = 1e30f;
                 for (int r = 0; r < 3 && he == hipSuccess; ++r) {
                     if (scrub) HIP_TRY(hipMemsetAsync(scrub, r, scrub_bytes, st));
-                    if (i > 0 && (rc = launch_op(p, p->ops[i - 1], true))) break;
+                    if (i > 0 && (rc = launch_op(p, p->ops[i - 1]))) break;
                     HIP_TRY(hipEventRecord(e0, st));
                     he = launch_conv_igemm(q, st);
                     HIP_TRY(hipEventRecord(e1, st));
@@ -1286,7 +1267,6 @@ extern "C" int accel_ctx_create(int device_id, accel_ctx** out)
     accel_ctx* c = new accel_ctx();
     c->device = device_id;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream1, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(ACCEL_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     *out = c;
@@ -1297,10 +1277,8 @@ extern "C" int accel_ctx_destroy(accel_ctx* ctx)
 {
     if (!ctx) return 0;
     hipStreamSynchronize(ctx->stream);
-    hipStreamSynchronize(ctx->stream1);
     hipStreamSynchronize(ctx->copy);
     hipStreamDestroy(ctx->stream);
-    hipStreamDestroy(ctx->stream1);
     hipStreamDestroy(ctx->copy);
     delete ctx;
     return 0;
@@ -1326,9 +1304,6 @@ extern "C" int accel_model_create(accel_ctx* ctx, accel_model** out)
 
 static void plan_free(accel_plan* p)
 {
-    for (Op& op : p->ops) if (op.done) hipEventDestroy(op.done);
-    if (p->ev_fork) hipEventDestroy(p->ev_fork);
-    if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->gexec) hipGraphExecDestroy(p->gexec);
     if (p->graph) hipGraphDestroy(p->graph);
     for (void* d : p->owned) hipFree(d);
@@ -1392,24 +1367,11 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         int rc = finalize_op(p, op);
         if (rc) return rc;
     }
-    if (p->two_streams) {
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-        for (Op& op : p->ops)
-            for (int j : op.waits) {
-                if (j < 0 || j >= (int)p->ops.size()) return fail(ACCEL_ERR_PLAN, "wait=%d out of range", j);
-                Op& prod = p->ops[j];
-                if (!prod.done) HIP_TRY(hipEventCreateWithFlags(&prod.done, hipEventDisableTiming));
-                prod.signal = true;
-            }
-    }
     if (p->ws_bytes) {
         HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
         poison(p->ws, p->ws_bytes);
         p->owned.push_back(p->ws);
-        p->ws1 = p->ws;
-        if (p->two_streams) { HIP_TRY(hipMalloc((void**)&p->ws1, p->ws_bytes)); p->owned.push_back(p->ws1); }
-        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = op.stream ? p->ws1 : p->ws;
+        for (Op& op : p->ops) if (op.kind == OP_CONV) op.conv.ws = p->ws;
     }
     HIP_TRY(hipDeviceSynchronize());
     const char* g = getenv("ACCEL_HIP_GRAPH");
@@ -1543,7 +1505,7 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
     for (int it = 0; it < iters && !rc; ++it) {
         for (size_t i = 0; i < n && !rc; ++i) {
             HIP_TRY(hipEventRecord(ev[2 * i], st));
-            rc = launch_op(p, p->ops[i], true);
+            rc = launch_op(p, p->ops[i]);
             HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
         }
         HIP_TRY(hipStreamSynchronize(st));
@@ -1558,12 +1520,12 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
     return rc;
 }
 
-// ---- diagnostics: the plan's ops one after the other on ONE stream (no graph, no side stream), and the arena ---------------
+// ---- diagnostics: the plan's ops one after the other, eagerly (no graph replay), then a host wait; and the arena -------------
 extern "C" int accel_plan_run_serial(accel_plan* p)
 {
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run_serial: plan not finalized");
     for (Op& op : p->ops) {
-        int rc = launch_op(p, op, true);
+        int rc = launch_op(p, op);
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));

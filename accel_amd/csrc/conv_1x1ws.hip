@@ -203,13 +203,7 @@ static hipError_t launch_ws(const ConvParams& p0, hipStream_t st, int cus)
     if (streams < 8) streams = 8;
     if (streams > ((mtiles + 7) / 8) * 8) streams = ((mtiles + 7) / 8) * 8;
     constexpr size_t lds = (size_t)(K * BN + 2 * K * BM + 2 * BN + 4 * 32 * 36) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, BM, BN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, BM, BN>), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL((conv1x1_ws_kernel<K, BM, BN>), dim3(streams * ngroups), dim3(256), lds, st, p, mtiles, ngroups, streams);
     return hipGetLastError();
 }

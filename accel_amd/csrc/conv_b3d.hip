@@ -23,9 +23,6 @@
 //     conflict-free for the 16-lane groups that serve a ds_read_b128 (MI355X_MICROARCH.md, LDS).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
-#include <mutex>
-#include <set>
-#include <utility>
 #include "kernels.h"
 #include "conv_common.h"
 #include "conv_epilogue.h"
@@ -238,20 +235,7 @@ static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
     constexpr size_t lds = (size_t)4 * (BM * 64 + NPL * BN * 32);
-    {
-        // the attribute belongs to (device, kernel): a second GPU in the process, or two threads finalising plans, must each see it set
-        static std::mutex mu;
-        static std::set<int> done;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(mu);
-        if (!done.count(dev)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            done.insert(dev);
-        }
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL>), lds); e != hipSuccess) return e;
     const int rowsB = (int)(p.w_bytes / ((unsigned)p.K_pad * 2u));
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_b3d_kernel<BM, BN, WGM, WGN, NPL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);

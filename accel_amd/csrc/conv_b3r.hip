@@ -267,16 +267,8 @@ static hipError_t launch_b3r(const ConvParams& p0, hipStream_t st)
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
     constexpr size_t lds = (size_t)2 * NPL * BM * 40 * sizeof(unsigned short);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL, NPL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL, NPL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL, NPL>), lds); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3r_kernel<BM, BN, WGM, WGN, false, ABL, NPL>), lds); e != hipSuccess) return e;
     const int rowsB = (int)(p.w_bytes / ((unsigned)p.K_pad * 2u));
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_b3r_kernel<BM, BN, WGM, WGN, true, ABL, NPL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);

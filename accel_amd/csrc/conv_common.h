@@ -2,6 +2,9 @@
 // buffer-resource loads / stores (hardware bounds check = zero padding without branches), small exact division.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,4 +50,21 @@ __device__ __forceinline__ void divmod_small(int a, int d, float inv_d, int& q, 
     r = a - q * d;
     if (r < 0) { --q; r += d; }
     else if (r >= d) { ++q; r -= d; }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (device, kernel): set once per pair, under a lock -- a second GPU in the
+// process (the reference's multi-context executor group) or two threads finalising plans must each find it set before a launch
+// that asks for more than 64 KB of dynamic LDS.  (Called from the launchers; the first launch of every kernel variant happens
+// eagerly at plan finalisation, never inside a stream capture.)
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
 }

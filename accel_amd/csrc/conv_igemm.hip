@@ -1003,14 +1003,7 @@ static hipError_t launch_cfg2(const ConvParams& p0, hipStream_t st)
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL, FAST>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL, FAST>), lds); e != hipSuccess) return e;
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WGM, WGN, BK, MID, ABL, FAST>), grid, dim3(64 * WGM * WGN), lds, st, p);
     hipError_t e = hipGetLastError();
@@ -1027,13 +1020,7 @@ static hipError_t launch_dma(const ConvParams& p0, hipStream_t st)
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
     constexpr size_t lds = (size_t)S * (BM + BN) * 32 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WGM, WGN, S>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WGM, WGN, S>), lds); e != hipSuccess) return e;
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WGM, WGN, S>), grid, dim3(64 * WGM * WGN), lds, st, p);
     hipError_t e = hipGetLastError();
@@ -1067,16 +1054,8 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
     p.NT = (p.Cout_store + BN - 1) / BN;
     constexpr bool WDMA = WGM * WGN == 8;      // measured: the DMA'd weight stream wins with 8 wavefronts (+5...14 %), loses with 4
     constexpr size_t lds = WDMA ? (size_t)(3 * BM * 40 + 2 * 3 * BN * 32) * sizeof(unsigned short) : (size_t)3 * (BM + BN) * 40 * sizeof(unsigned short);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), lds); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>), lds); e != hipSuccess) return e;
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
     static const char* nofast = getenv("ACCEL_B3_NOFAST");      // debugging: the general (per-lane table) load path for every layer
     if (p.Cin % 32 == 0 && !(nofast && nofast[0] == '1')) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);

@@ -248,13 +248,7 @@ hipError_t launch_conv_stem(const ConvParams& p0, hipStream_t st)
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_f32_kernel), STEM_LDS); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_stem_f32_kernel, dim3(grid), dim3(256), STEM_LDS, st, p, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }

@@ -378,13 +378,7 @@ hipError_t launch_conv_wino(const ConvParams& p0, hipStream_t st)
     p.wino_T = p.M / 4;
     p.MT = (p.wino_T + TT - 1) / TT;
     p.NT = p.wino_rows / KK;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_f32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_f32_kernel), WINO_LDS); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(512), WINO_LDS, st, p);
     if (p.ksplit > 1) {
         hipError_t e = hipGetLastError();

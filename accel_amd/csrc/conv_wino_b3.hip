@@ -551,15 +551,7 @@ hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_
     p.NT = p.wino_rows / KK;
     const size_t lds = union_loader ? WB_LDS_U : WB_LDS;
     auto go = [&](auto kern) -> hipError_t {
-        static std::vector<const void*> attr_done;      // one hipFuncSetAttribute per kernel and process
-        const void* kp = reinterpret_cast<const void*>(kern);
-        bool done = false;
-        for (const void* d_ : attr_done) done |= d_ == kp;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done.push_back(kp);
-        }
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(512), lds, st, p);
         return hipSuccess;
     };

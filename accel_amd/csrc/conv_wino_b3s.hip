@@ -364,12 +364,7 @@ hipError_t launch_conv_wino_b3s(const ConvParams& p0, hipStream_t st)
     p.wino_T = p.M / 4;
     p.MT = (int)conv_wino_b3s_blocks(p, &p.wino_bhs);
     p.NT = p.wino_rows / KKS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_b3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WBS_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_b3s_kernel), WBS_LDS); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_wino_b3s_kernel, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(256), WBS_LDS, st, p);
     if (p.ksplit > 1) {
         hipError_t e = hipGetLastError();

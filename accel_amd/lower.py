@@ -53,7 +53,6 @@ class VBuf(object):
         self.id, self.Cs, self.H, self.W, self.space, self.N = bid, Cs, H, W, space, N
         self.first, self.last = None, None
         self.off = 0
-        self.streams = set()
 
     @property
     def nbytes(self):
@@ -93,7 +92,7 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, multi_stream=False, fold_linear=True, feat_slot=None):
+    def __init__(self, sym, input_shapes, ncls=19, fold_linear=True, feat_slot=None):
         self.sym = sym
         self.fold_linear = bool(fold_linear)
         # Ping-pong of the propagated feature (non-key graphs): a warp cannot run in place, so the plan either warps into
@@ -142,25 +141,6 @@ class Lowering(object):
                 if n.op == "Crop" and idx == 1:
                     continue   # shape reference only
                 self.cons.setdefault(id(i), []).append(n)
-        # variable dependencies of every node: ops that need only `data` (the per-frame correction
-        # branch) are independent of FlowNet / warp / L head until the fusion and go to a second stream
-        self.deps = {}
-        for n in self.nodes:
-            if n.op == "null":
-                self.deps[id(n)] = frozenset([n.name]) if n.name in ("data", "data_key", "feat_key", "data_ref") else frozenset()
-            else:
-                d = frozenset()
-                for idx, i in enumerate(n.inputs):
-                    if n.op == "Crop" and idx == 1:
-                        continue
-                    d |= self.deps.get(id(i), frozenset())
-                self.deps[id(n)] = d
-        compute = [n for n in self.nodes if n.op in ("Convolution", "Deconvolution", "DeformableConvolution")]
-        only_data = [n for n in compute if self.deps[id(n)] == frozenset(["data"])]
-        self.two_streams = bool(multi_stream) and 0 < len(only_data) < len(compute)
-        self.cur_stream = 0
-        self.last_writer = {}   # buffer key -> {stream: index of the last op that wrote it}
-        self.last_reader = {}   # buffer key -> {stream: index of the last op that read it}
         data_shape = input_shapes["data"]
         self.N, self.H, self.W = int(data_shape[0]), int(data_shape[2]), int(data_shape[3])
         self.nsfx = "" if self.N == 1 else ":%d" % self.N     # batch suffix of literal buffer references
@@ -237,41 +217,9 @@ class Lowering(object):
             if v is not None and v.buf.space == "A":
                 v.buf.touch(idx)
         args = dict(args)
-        st = self.cur_stream if self.two_streams else 0
-        for v in list(reads) + list(writes):
-            if v is not None:
-                v.buf.streams.add(st)
-        # Cross-stream ordering (two-stream plans).  Per buffer and stream the plan remembers the LAST op that wrote and the
-        # last op that read it; in-order execution inside a stream covers the older ones.  A read waits for the last writer on
-        # every other stream (several producers may fill channel slices of one concat buffer from different streams); a
-        # write waits for the other streams' last readers and writers of that buffer as well (write-after-read / -write).
-        waits = set()
-        for v in reads:
-            if v is None:
-                continue
-            for s_, w in self.last_writer.get(self._bkey(v), {}).items():
-                if s_ != st:
-                    waits.add(w)
-        for v in writes:
-            if v is None:
-                continue
-            k = self._bkey(v)
-            for s_, w in self.last_writer.get(k, {}).items():
-                if s_ != st:
-                    waits.add(w)
-            for s_, r in self.last_reader.get(k, {}).items():
-                if s_ != st:
-                    waits.add(r)
-        for v in reads:
-            if v is not None:
-                self.last_reader.setdefault(self._bkey(v), {})[st] = idx
-        for v in writes:
-            if v is not None:
-                self.last_writer.setdefault(self._bkey(v), {})[st] = idx
-        if self.two_streams:
-            args["stream"] = st
-            if waits:
-                args["wait"] = ",".join(str(w) for w in sorted(waits))
+        # every plan runs on ONE stream, in list order (a two-stream lowering existed in rounds 1-3 and was removed: on this stack a
+        # side-stream kernel could read stale granules of an earlier same-stream kernel's output while a bandwidth-heavy kernel ran
+        # on the other hardware queue -- DESIGN.md 7)
         n = self.N if n is None else n
         force = _forced_tiles().get(args.get("name"))
         if force is not None and kind == "conv":
@@ -742,7 +690,6 @@ class Lowering(object):
             if id(n) in self.absorbed or n.op in ("null", "_group"):
                 continue
             op = n.op
-            self.cur_stream = 1 if self.deps.get(id(n)) == frozenset(["data"]) else 0
             if op == "Deconvolution" and self._is_upsampler(n):
                 continue
             if op == "Crop" and self._is_upsampler(n.inputs[0]):
@@ -801,12 +748,7 @@ class Lowering(object):
         return self
 
     def assign_offsets(self):
-        """Greedy first-fit arena packing over [first, last] op-index lifetimes.
-
-        Op-list order is the execution order only WITHIN a stream: the side stream forks at the
-        start of the plan, so its ops overlap in time with every compute-stream op.  Buffers are
-        therefore packed per stream into disjoint arena regions; buffers touched by both streams
-        (join inputs) get private space."""
+        """Greedy first-fit arena packing over [first, last] op-index lifetimes (list order = execution order)."""
         live = [b for b in self.bufs if b.first is not None]
         import os
         if os.environ.get("ACCEL_ARENA_NO_REUSE") == "1":
@@ -834,13 +776,7 @@ class Lowering(object):
                 total = max(total, off + size)
             return total
 
-        total = pack([b for b in live if b.streams <= {0}], 0)
-        total += pack([b for b in live if b.streams == {1}], total)
-        for b in live:
-            if len(b.streams) > 1:
-                b.off = total
-                total += (b.nbytes + ALIGN - 1) // ALIGN * ALIGN
-        self.arena_bytes = total
+        self.arena_bytes = pack(live, 0)
 
     def text(self, graph=True, conv_dtype="f32"):
         lines = ["# accel_amd plan: %d ops, arena %.1f MB, %.2f GFLOP" % (len(self.ops), self.arena_bytes / 1e6, self.total_flops / 1e9)]
@@ -907,6 +843,6 @@ def init_plan_text(name, d):
                                            d["from"], cin, _r4(cin), H, W, sfx, 2.0 * N * H * W * cin * cout)]) + "\n"
 
 
-def lower(sym, input_shapes, graph=True, multi_stream=False, conv_dtype="f32", fold_linear=True, feat_slot=None):
-    lw = Lowering(sym, input_shapes, multi_stream=multi_stream, fold_linear=fold_linear, feat_slot=feat_slot).run()
+def lower(sym, input_shapes, graph=True, conv_dtype="f32", fold_linear=True, feat_slot=None):
+    lw = Lowering(sym, input_shapes, fold_linear=fold_linear, feat_slot=feat_slot).run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

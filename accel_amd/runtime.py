@@ -350,7 +350,7 @@ class Plan(object):
         return out
 
     def run_serial(self):
-        """diagnostics: every op in list order on the context stream (no graph, no side stream), then a host wait"""
+        """diagnostics: every op in list order on the context stream (no graph replay), then a host wait"""
         check(lib().accel_plan_run_serial(self.handle))
 
     def arena(self):

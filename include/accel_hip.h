@@ -98,7 +98,7 @@ int accel_tune_stats(int* replayed, int* timed, int* shipped_entries);
 int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms);
 
 /* Diagnostics (scripts/debug, tests): the ops of a finalized plan launched one after the other on the context stream --
- * no captured graph, no side stream -- followed by a host wait; and a host copy of a byte range of the plan's activation
+ * no captured graph -- followed by a host wait; and a host copy of a byte range of the plan's activation
  * arena (arena_bytes, if given, receives its size; host_dst may be NULL to query only).  Comparing the arena after a
  * normal accel_plan_run with the arena after accel_plan_run_serial of the same bound plan names the first op whose
  * output depends on the schedule. */

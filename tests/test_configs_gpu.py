@@ -54,22 +54,36 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
 def test_winograd_bf16_geometry_on_every_eligible_layer_vs_oracle(demo_cfg, monkeypatch, tmp_path, geometry):
     """The launch-geometry table decides per layer; this test does not depend on what it decided: EVERY layer that can take
     the Winograd-on-bf16 geometry 41 / 42 / 43 (every 3x3 / stride 1 layer of the two ResNet branches with channels in
-    multiples of 16 -- the FlowNet layers are withheld by the lowering) is forced onto it (ACCEL_WB3_FORCE,
-    a private tune cache so that nothing is replayed), and a key + a non-key frame of Accel-18 at 512x1024 are compared with
+    multiples of 16 -- the FlowNet layers are withheld by the lowering) is forced onto it (ACCEL_WB3_FORCE: applied
+    to the plans directly, the launch-geometry table is neither read nor written for those layers), and a key + a non-key frame of Accel-18 at 512x1024 are compared with
     the oracle at the whole-graph tolerance."""
-    from accel_amd import demo
+    from accel_amd import demo, runtime
     from accel_amd.core import tester
     monkeypatch.setenv("ACCEL_WB3_FORCE", str(geometry))
-    monkeypatch.setenv("ACCEL_TUNE_CACHE", str(tmp_path / "forced.tune"))
     H, W, interval = 512, 1024, 2
     demo_cfg.SCALES[0] = (H, W)
     arg, aux = synth.model_params("18", H, W, demo_cfg)
     frames = synth.make_clip(H, W, 2)
+    data = demo.build_batches(frames, demo_cfg)
     try:
-        outs = demo.run_clip("18", demo_cfg, arg, aux, frames, interval)
-        from accel_amd import runtime
-        forced = [l for l in open(str(tmp_path / "forced.tune")) if not l.startswith("#") and int(l.split()[16]) == geometry]
-        assert len(forced) >= 8, "the forced geometry must have been applied to the 3x3 layers (%d table lines)" % len(forced)
+        lib = runtime.lib()
+        import ctypes
+        before = [ctypes.c_int() for _ in range(3)]
+        lib.accel_tune_stats(*[ctypes.byref(v) for v in before])
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        outs = []
+        for idx, arrays in enumerate(data):
+            logits, labels = r.step(idx, arrays, interval)
+            outs.append((logits.asnumpy(), np.uint8(np.squeeze(labels.asnumpy()))))
+        forced = 0
+        for pred in (r.key_predictor, r.cur_predictor):
+            forced += sum(1 for o in pred.plan_for(H, W, 1)[0].ops() if o["kind"] == "conv" and o["tile"] == geometry)
+        assert forced >= 8, "the forced geometry must have been applied to the 3x3 layers (%d launches)" % forced
+        # the forced geometry lives in the plans only: nothing was timed for those layers and the process-wide table is untouched,
+        # so what later tests of this session replay does not depend on this one having run
+        after = [ctypes.c_int() for _ in range(3)]
+        lib.accel_tune_stats(*[ctypes.byref(v) for v in after])
+        assert after[2].value == before[2].value
     finally:
         tester.release_models()
     P = dict(arg)

@@ -494,7 +494,7 @@ def test_batched_clips_match_single_clip_runs(demo_cfg, version):
         tester.release_models()
 
 
-@pytest.mark.parametrize("version,key_interval", [("18", 5), ("101", 3), ("50", 5)])
+@pytest.mark.parametrize("version,key_interval", [("18", 5), ("101", 3), ("50", 5), ("34", 3)])
 def test_train_symbol_forward(demo_cfg, version, key_interval):
     """get_train_symbol, forward only (accel_18.py:31-119, accel_101.py:31-102): `data_ref` = key frame + intermediate
     frames, `data` = the labelled frame; all frame pairs through ONE FlowNet batch, the key feature warped once per pair,

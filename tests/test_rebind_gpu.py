@@ -8,13 +8,12 @@ context, streams, arena, weights each time -- at the bench size, and
     (accel_plan_run_serial), for the lowering with and without the linear folds.
 
 This is the regression test of the round-2 "binding-dependent wrong frames" report.  What that was (DESIGN.md 7,
-"two-stream hazard"; scripts/debug/twostream_bisect.py is the tool that found it): with TWO streams, whenever the two HIP
-streams of a binding land on different hardware queues, a kernel of the side stream can read 256-byte granules of an
-earlier same-stream kernel's output as if they had not been written while a bandwidth-heavy kernel runs on the other
-queue.  Plans are lowered for ONE stream by default since; the last test here exercises the opt-in two-stream lowering
-and REPORTS (does not assert) how many bindings deviate, so the log of every GPU run keeps the evidence current."""
+"two-stream hazard", logs in profiles/r03_twostream/): with TWO streams, whenever the two HIP streams of a binding landed on
+different hardware queues, a kernel of the side stream could read 256-byte granules of an earlier same-stream kernel's output as
+if they had not been written while a bandwidth-heavy kernel ran on the other queue.  No stand-alone reproducer was found, so the
+two-stream lowering and its switch were REMOVED in round 4 (a switch that is wrong in 7 bindings of 8 has no place in the
+product path); what stays is the contract: an executor is deterministic per bind."""
 import os
-import warnings
 
 import numpy as np
 import pytest
@@ -43,8 +42,6 @@ def test_every_binding_computes_the_same_frames(demo_cfg, version, binds):
     for it in range(binds):
         r, outs = _bind_and_run(version, demo_cfg, arg, aux, data)
         try:
-            plan, lw = r.cur_predictor.plan_for(H, W, 1)
-            assert not lw.two_streams, "the default lowering must be single-stream"
             if ref is None:
                 ref = outs
             for t, (a, b) in enumerate(zip(outs, ref)):
@@ -74,39 +71,3 @@ def test_graph_replay_equals_the_serial_run_of_the_same_binding(demo_cfg, monkey
                 it, float(np.abs(outs[1] - serial).max()))
         finally:
             r.close()
-
-
-def test_two_stream_opt_in_is_reported_not_trusted(demo_cfg, monkeypatch, capsys):
-    """ACCEL_MULTI_STREAM=1 (opt-in, warns): the layer-by-layer lowering on two streams, eight bindings, each compared
-    with the serial run of the same binding.  The count of deviating bindings is REPORTED: on the stack of rounds 2-3 about
-    half of them deviate (errors of 0.2-1.5 on logits of +-110); the serial runs must all agree with each other."""
-    from accel_amd import demo
-    from accel_amd.core import tester
-    monkeypatch.setenv("ACCEL_FOLD_LINEAR", "0")
-    monkeypatch.setenv("ACCEL_MULTI_STREAM", "1")
-    monkeypatch.setattr(tester.Predictor, "_warned_multi", False, raising=False)
-    demo_cfg.SCALES[0] = (H, W)
-    arg, aux = synth.model_params("18", H, W, demo_cfg)
-    data = demo.build_batches(synth.make_clip(H, W, 2), demo_cfg)
-    deviating, serial_ref = [], None
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        for it in range(8):
-            r, outs = _bind_and_run("18", demo_cfg, arg, aux, data, nframes=2)
-            try:
-                plan, lw = r.cur_predictor.plan_for(H, W, 1)
-                assert lw.two_streams
-                m = r.cur_predictor._model
-                plan.run_serial()
-                serial = m.read("logits", (1, 19, H, W))
-                if serial_ref is None:
-                    serial_ref = serial
-                assert np.array_equal(serial, serial_ref), "the serial runs of two bindings differ"
-                if not np.array_equal(outs[1], serial):
-                    deviating.append((it, float(np.abs(outs[1] - serial).max())))
-            finally:
-                r.close()
-    assert any("ACCEL_MULTI_STREAM" in str(w.message) for w in caught), "the opt-in must warn"
-    with capsys.disabled():
-        print("\n[two-stream hazard] %d of 8 opt-in two-stream bindings deviate from their own serial run: %s"
-              % (len(deviating), ", ".join("bind %d: %.3g" % d for d in deviating) or "none"))
