@@ -108,6 +108,7 @@ struct BufRef {
     size_t off = 0;
     int C = 0, Cs = 0, H = 0, W = 0;
     int N = 1;              // images in the batch; image n starts n*H*W pixels (n*H*W*Cs floats) after image 0
+    int esize = 4;          // bytes per element: 4 = fp32, 2 = half (":h" tag; f16-mode plans, convolution views only)
     bool set = false;
     float* ptr = nullptr;   // resolved at finalize
     size_t img() const { return (size_t)H * W * Cs; }   // floats per image
@@ -194,6 +195,8 @@ static int parse_buf(const KV& kv, const char* key, BufRef& r)
     std::stringstream ss(it->second);
     std::string tok;
     while (std::getline(ss, tok, ':')) f.push_back(tok);
+    r.esize = 4;
+    if (f.size() == 8 && f[7] == "h") { r.esize = 2; f.pop_back(); }      // half storage: space:off:C:Cs:H:W:N:h
     if (f.size() != 6 && f.size() != 7) return fail(ACCEL_ERR_PLAN, "bad buffer reference %s=%s", key, it->second.c_str());
     r.space = f[0];
     r.off = strtoull(f[1].c_str(), nullptr, 10);
@@ -325,12 +328,14 @@ static int parse_plan(accel_plan* p, const char* text)
     return 0;
 }
 
-static int resolve(accel_plan* p, BufRef& r, const char* what)
+static int resolve(accel_plan* p, BufRef& r, const char* what, bool half_ok = false)
 {
     if (!r.set) return fail(ACCEL_ERR_PLAN, "missing buffer '%s'", what);
+    if (r.esize != 4 && !half_ok) return fail(ACCEL_ERR_PLAN, "buffer '%s': only convolutions of an f16-mode plan take half views", what);
+    if (r.esize == 2 && (r.space != "A" || r.Cs % 8 || r.off % 16)) return fail(ACCEL_ERR_PLAN, "buffer '%s': a half view lives in the arena, 16-byte aligned, Cs %% 8 == 0", what);
     if (r.space == "A") {
         // a view's last pixel row may stop short of Cs; be lenient by C
-        const size_t need_min = r.off + (((size_t)r.N * r.H * r.W - 1) * r.Cs + r.C) * sizeof(float);
+        const size_t need_min = r.off + (((size_t)r.N * r.H * r.W - 1) * r.Cs + r.C) * (size_t)r.esize;
         if (need_min > p->arena_bytes) return fail(ACCEL_ERR_PLAN, "buffer '%s' exceeds arena (%zu > %zu)", what, need_min, p->arena_bytes);
         r.ptr = reinterpret_cast<float*>(p->arena + r.off);
     } else {
@@ -431,9 +436,9 @@ static int finalize_conv(accel_plan* p, Op& op)
     int rc;
     if ((rc = parse_buf(kv, "in", op.a)) || (rc = parse_buf(kv, "out", op.b)) ||
         (rc = parse_buf(kv, "out2", op.c)) || (rc = parse_buf(kv, "res", op.d))) return rc;
-    if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "out"))) return rc;
+    if ((rc = resolve(p, op.a, "in", true)) || (rc = resolve(p, op.b, "out", true))) return rc;
     if (op.c.set && (rc = resolve(p, op.c, "out2"))) return rc;
-    if (op.d.set && (rc = resolve(p, op.d, "res"))) return rc;
+    if (op.d.set && (rc = resolve(p, op.d, "res", true))) return rc;
 
     const std::string wname = kv_str(kv, "w");
     const HostParam* w = get_param(m, wname);
@@ -601,9 +606,16 @@ static int finalize_conv(accel_plan* p, Op& op)
         return fail(ACCEL_ERR_PLAN, "conv %s: batch sizes of the views differ", op.name.c_str());
     c.M = op.a.N * c.Ho * c.Wo;
     auto extent = [](const BufRef& r, int cuse) {
-        const size_t b = (((size_t)r.N * r.H * r.W - 1) * r.Cs + cuse) * sizeof(float);
+        const size_t b = (((size_t)r.N * r.H * r.W - 1) * r.Cs + cuse) * (size_t)r.esize;
         return (unsigned)(b > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : b);
     };
+    c.x_half = op.a.esize == 2; c.y_half = op.b.esize == 2; c.res_half = op.d.set && op.d.esize == 2;
+    if (c.x_half || c.y_half || c.res_half) {
+        // half views are read / written by the fp16 form of conv_b3d.hip alone
+        if (c.f16 != 1 || !c.wb3r || c.Cin % 16 || op.c.set)
+            return fail(ACCEL_ERR_PLAN, "conv %s: half views need an f16-mode layer with Cin %% 16 == 0, more than 4 output channels and a "
+                                        "single output (plan option dtype=f16, ACCEL_B3R != 0)", op.name.c_str());
+    }
     if ((size_t)op.a.N * op.a.img() * 4 > 0xFFFFFFF0ull || (size_t)op.b.N * op.b.img() * 4 > 0xFFFFFFF0ull)
         return fail(ACCEL_ERR_PLAN, "conv %s: a batched view exceeds the 4 GiB a buffer resource can address", op.name.c_str());
     c.x_bytes = extent(op.a, c.Cin > op.a.Cs ? op.a.Cs : c.Cin);
@@ -626,7 +638,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 int* t = &tab[((size_t)cls * (G + slack) + g) * 4];
                 if (g >= G || tap >= c.kh * c.kw) { t[0] = -(1 << 28); continue; }
                 t[0] = ky * c.dh; t[1] = kx * c.dw;
-                t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * 4;
+                t[2] = ((ky * c.dh * c.W + kx * c.dw) * c.xCs + ci) * op.a.esize;
             }
         void* dt = nullptr;
         if ((rc = dev_upload(p, tab.data(), tab.size() * sizeof(int), &dt))) return rc;
@@ -1092,7 +1104,20 @@ static int autotune_plan(accel_plan* p)
         if (op.kind != OP_CONV || op.conv.force_tile >= 0 || op.conv.narrow) continue;
         ConvParams c = op.conv;
         std::vector<Cand>& cs = cands[i];
-        if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
+        if (c.x_half || c.y_half || c.res_half) {
+            // a layer with half views runs on the fp16 form of conv_b3d.hip: 82 / 83 / 84 / 85 / 88 / 89 by tile shape
+            for (int t : {CONV_TILE_B3D, CONV_TILE_B3D + 1, CONV_TILE_B3D + 2, CONV_TILE_B3D + 3, CONV_TILE_B3D + 6, CONV_TILE_B3D + 7}) {
+                if ((t == CONV_TILE_B3D || t == CONV_TILE_B3D + 1) && c.Cout_store <= 128) continue;      // 256-column tiles
+                if ((t != CONV_TILE_B3D + 6) && c.Cout_store <= 64) continue;                              // 64 channels: the 128x64 tile only
+                cs.push_back({t, 0, 0});
+                ConvParams q = c;
+                const size_t base = conv_apply(q, t, 0, 0);
+                const int ks0 = q.ksplit;
+                if (conv_apply(q, t, 1024, 0) && q.ksplit != ks0) cs.push_back({t, 1024, 0});
+                if (base) cs.push_back({t, 0, 1});
+            }
+        }
+        else if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
         else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
         else {
             // (a layer that runs in fp16-MFMA mode stays on the fp16 kernel: "operands of every convolution with Cin % 8 == 0 and
@@ -1190,7 +1215,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0) + 2048 * c.x_half + 4096 * c.y_half + 8192 * c.res_half, c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it != g_tune_cache.end()) {

@@ -23,6 +23,7 @@
 //     conflict-free for the 16-lane groups that serve a ds_read_b128 (MI355X_MICROARCH.md, LDS).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "conv_common.h"
 #include "conv_epilogue.h"
@@ -42,17 +43,22 @@ __device__ __forceinline__ void split3_pair_d(float v0, float v1, unsigned& q0, 
     q2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
 }
 
-// NPL = 3: bf16x3; NPL = 1: the fp16-MFMA mode (pixels rounded to half after the fragment read, one plane of half-rounded weights)
-template <int BM, int BN, int WGM, int WGN, int NPL = 3>
+// NPL = 3: bf16x3; NPL = 1: the fp16-MFMA mode (pixels rounded to half after the fragment read, one plane of half-rounded weights);
+// XH (NPL = 1 only): the pixel operand is STORED as half (ConvParams::x_half): rows of 32 bytes per stage, the fragment is what the
+// DMA brought, no conversion at all; the epilogue of the NPL = 1 forms may read a half residual and write half (conv_epilogue_h)
+template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!XH || NPL == 1, "half pixel storage belongs to the fp16 form");
     constexpr int NW = WGM * WGN, NS = 4;
     constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
-    constexpr int A_BYTES = BM * 64, B_BYTES = NPL * BN * 32, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = BM / 16, NB = NPL * BN / 32;      // DMA instructions (1 KB each) per stage
-    static_assert(NA % NW == 0 && NB % NW == 0, "the pieces of a stage must split evenly over the wavefronts");
-    constexpr int LA = NA / NW, LB = NB / NW, L = LA + LB;
+    constexpr int A_ROW = XH ? 32 : 64;                   // bytes of a pixel row per stage (16 of K)
+    constexpr int A_BYTES = BM * A_ROW, B_BYTES = NPL * BN * 32, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, NP = NA + NB;      // DMA pieces (1 KB = one wave instruction) per stage
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tiles are whole kilobytes");
+    // piece q of a stage belongs to wavefront q % NW: every wavefront issues LMAX or LMAX - 1 pieces per stage
+    constexpr int LMAX = (NP + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -75,35 +81,41 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t wall = make_rsrc(wbase, (unsigned)(2 * (NPL - 1) * wplane) + (unsigned)((size_t)rowsB * p.K_pad * 2) + (unsigned)(rowsB * 128));
     const int HoWo = p.Ho * p.Wo;
+    constexpr int XB = XH ? 2 : 4;      // bytes per stored pixel value
 
     // ---- DMA pieces of this wavefront ----------------------------------------------------------------------------------------
-    // pixel piece q (rows 16q .. 16q+15): lane -> (row = lane >> 2, physical slot = lane & 3), fetches K quad slot ^ ((row >> 2) & 3)
-    int a_iy0[LA], a_ix0[LA];
-    unsigned a_off[LA];
+    // fp32 pixel piece q (rows 16q ..): lane -> (row = lane >> 2, physical slot = lane & 3), fetches K quad slot ^ ((row >> 2) & 3)
+    // half pixel piece q (rows 32q ..) and weight piece (plane q / (BN / 32), rows 32 (q % (BN / 32)) ..): lane -> (row = lane >> 1,
+    // slot = lane & 1), fetches the 16-byte half slot ^ ((row >> 3) & 1)
+    bool pc_on[LMAX], pc_a[LMAX];
+    int pc_lds[LMAX], pc_iy0[LMAX], pc_ix0[LMAX];
+    unsigned pc_off[LMAX];
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-        const int r = (wave * LA + j) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        const int m = m0 + r;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int n = mm / HoWo, rem = mm - n * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_iy0[j] = ok ? oy * p.sh - ph : -(1 << 28);
-        a_ix0[j] = ox * p.sw - pw;
-        a_off[j] = (unsigned)((((n * p.H + a_iy0[j]) * p.W + a_ix0[j]) * p.xCs + c * 4) * 4);
+    for (int t = 0; t < LMAX; ++t) {
+        const int q = wave + t * NW;
+        pc_on[t] = q < NP;
+        pc_a[t] = q < NA;
+        pc_lds[t] = q * 1024;           // pixel pieces first, then the weight planes: plane pl, row block rb at A_BYTES + (pl * (BN / 32) + rb) KB
+        pc_iy0[t] = pc_ix0[t] = 0;
+        if (pc_a[t]) {
+            const int r = XH ? q * 32 + (lane >> 1) : q * 16 + (lane >> 2);
+            const int cbyte = XH ? (((lane & 1) ^ ((r >> 3) & 1)) * 16) : (((lane & 3) ^ ((r >> 2) & 3)) * 16);
+            const int m = m0 + r;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int n = mm / HoWo, rem = mm - n * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            pc_iy0[t] = ok ? oy * p.sh - ph : -(1 << 28);
+            pc_ix0[t] = ox * p.sw - pw;
+            pc_off[t] = (unsigned)((((n * p.H + pc_iy0[t]) * p.W + pc_ix0[t]) * p.xCs) * XB + cbyte);
+        } else {
+            const int qb = q - NA, pl = qb / (BN / 32), rb = qb % (BN / 32);
+            const int n = rb * 32 + (lane >> 1);
+            const int h = (lane & 1) ^ ((n >> 3) & 1);
+            pc_off[t] = (unsigned)pl * (unsigned)(2 * wplane) + (unsigned)((n0 + n) * 32 + h * 16);
+        }
     }
-    // weight piece q (plane q / (BN / 32), rows 32 (q % (BN / 32)) ..): lane -> (row = lane >> 1, slot = lane & 1), fetches half slot ^ ((row >> 3) & 1)
-    unsigned b_off[LB];
-    int b_lds[LB];
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-        const int q = wave * LB + j, pl = q / (BN / 32), rb = q % (BN / 32);
-        const int n = rb * 32 + (lane >> 1);
-        const int h = (lane & 1) ^ ((n >> 3) & 1);
-        b_off[j] = (unsigned)pl * (unsigned)(2 * wplane) + (unsigned)((n0 + n) * 32 + h * 16);
-        b_lds[j] = A_BYTES + pl * BN * 32 + rb * 1024;
-    }
+    const bool full = (NP % NW == 0) || wave < NP % NW;      // this wavefront issues LMAX pieces per stage (else LMAX - 1)
     const unsigned hstep = (unsigned)rowsB * 32u;      // bytes of one half step of one plane
 
     const int KT_all = p.K_pad / 32;
@@ -122,15 +134,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
         tk_next = ktab[(s + 1) * 4];         // requested a stage ahead of its use
         unsigned char* st = smem_d + slot * STAGE;
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const int iy = a_iy0[j] + tk.x, ix = a_ix0[j] + tk.y;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_d)(st + (wave * LA + j) * 1024), 16,
-                                                     ok ? a_off[j] + (unsigned)tk.z : OOB, 0, 0, 0);
+        for (int t = 0; t < LMAX; ++t) {
+            if (!pc_on[t]) continue;         // wave-uniform
+            if (pc_a[t]) {
+                const int iy = pc_iy0[t] + tk.x, ix = pc_ix0[t] + tk.y;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_d)(st + pc_lds[t]), 16, ok ? pc_off[t] + (unsigned)tk.z : OOB, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wall, (lds_ptr_d)(st + pc_lds[t]), 16, pc_off[t], (unsigned)s * hstep, 0, 0);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wall, (lds_ptr_d)(st + b_lds[j]), 16, b_off[j], (unsigned)s * hstep, 0, 0);
+    };
+    // my pieces of the older stages have landed when at most `stages` newer stages of mine are outstanding
+    auto wait_stages = [&](auto stages_c) {
+        constexpr int n = decltype(stages_c)::value;
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n * LMAX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n * (LMAX - 1)) : "memory");
     };
 
     // ---- fragment addressing ----------------------------------------------------------------------------------------------------
@@ -138,9 +157,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     int a_lo[MI], a_hi[MI], b_ad[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int r = (wm * MI + i) * 32 + frow, x = (r >> 2) & 3;
-        a_lo[i] = r * 64 + ((2 * fh) ^ x) * 16;
-        a_hi[i] = r * 64 + ((2 * fh + 1) ^ x) * 16;
+        const int r = (wm * MI + i) * 32 + frow;
+        if constexpr (XH) {
+            a_lo[i] = r * 32 + (fh ^ ((r >> 3) & 1)) * 16;
+            a_hi[i] = 0;
+        } else {
+            const int x = (r >> 2) & 3;
+            a_lo[i] = r * 64 + ((2 * fh) ^ x) * 16;
+            a_hi[i] = r * 64 + ((2 * fh + 1) ^ x) * 16;
+        }
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -161,18 +186,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
         const unsigned char* st = smem_d + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_lo[i]), hi = *reinterpret_cast<const f32x4*>(st + a_hi[i]);
-            if constexpr (NPL == 1) {
-                f16x8d h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = (_Float16)lo[e]; h[4 + e] = (_Float16)hi[e]; }
-                fa[set][i][0] = __builtin_bit_cast(i32x4, h);
+            if constexpr (XH) {
+                fa[set][i][0] = *reinterpret_cast<const i32x4*>(st + a_lo[i]);
             } else {
-                unsigned x0, x1, x2;
-                split3_pair_d(lo[0], lo[1], x0, x1, x2); fa[set][i][0][0] = (int)x0; fa[set][i][1][0] = (int)x1; fa[set][i][2][0] = (int)x2;
-                split3_pair_d(lo[2], lo[3], x0, x1, x2); fa[set][i][0][1] = (int)x0; fa[set][i][1][1] = (int)x1; fa[set][i][2][1] = (int)x2;
-                split3_pair_d(hi[0], hi[1], x0, x1, x2); fa[set][i][0][2] = (int)x0; fa[set][i][1][2] = (int)x1; fa[set][i][2][2] = (int)x2;
-                split3_pair_d(hi[2], hi[3], x0, x1, x2); fa[set][i][0][3] = (int)x0; fa[set][i][1][3] = (int)x1; fa[set][i][2][3] = (int)x2;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_lo[i]), hi = *reinterpret_cast<const f32x4*>(st + a_hi[i]);
+                if constexpr (NPL == 1) {
+                    f16x8d h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (_Float16)lo[e]; h[4 + e] = (_Float16)hi[e]; }
+                    fa[set][i][0] = __builtin_bit_cast(i32x4, h);
+                } else {
+                    unsigned x0, x1, x2;
+                    split3_pair_d(lo[0], lo[1], x0, x1, x2); fa[set][i][0][0] = (int)x0; fa[set][i][1][0] = (int)x1; fa[set][i][2][0] = (int)x2;
+                    split3_pair_d(lo[2], lo[3], x0, x1, x2); fa[set][i][0][1] = (int)x0; fa[set][i][1][1] = (int)x1; fa[set][i][2][1] = (int)x2;
+                    split3_pair_d(hi[0], hi[1], x0, x1, x2); fa[set][i][0][2] = (int)x0; fa[set][i][1][2] = (int)x1; fa[set][i][2][2] = (int)x2;
+                    split3_pair_d(hi[2], hi[3], x0, x1, x2); fa[set][i][0][3] = (int)x0; fa[set][i][1][3] = (int)x1; fa[set][i][2][3] = (int)x2;
+                }
             }
         }
     };
@@ -206,39 +235,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     issue(s_begin, 0);
     issue(s_begin + 1, 1);
     issue(s_begin + 2, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+    wait_stages(std::integral_constant<int, 2>());
     __builtin_amdgcn_s_barrier();
     read_split_a(0, 0);
     for (int k = 0; k < ns; k += 2) {
         // even stage: fragments in set 0
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");        // my pieces of stage k+1 have landed (k+2 may be in flight)
+        wait_stages(std::integral_constant<int, 1>());                   // my pieces of stage k+1 have landed (k+2 may be in flight)
         __builtin_amdgcn_s_barrier();                                    // stage k+1 complete for everyone; slot (k+3) % 4 no longer read
         issue(s_begin + k + 3, (k + 3) & 3);
         read_split_a((k + 1) & 3, 1);
         mma(k & 3, 0);
         // odd stage: fragments in set 1
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        wait_stages(std::integral_constant<int, 1>());
         __builtin_amdgcn_s_barrier();
         issue(s_begin + k + 4, (k + 4) & 3);
         read_split_a((k + 2) & 3, 0);
         mma((k + 1) & 3, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may land after the block has given its LDS back
-    conv_epilogue<MI, NI, WGN, (MI * NI > 4)>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+    if constexpr (NPL == 1) conv_epilogue_h<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+    else conv_epilogue<MI, NI, WGN, (MI * NI > 4)>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NPL = 3>
+template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false>
 static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
-    constexpr size_t lds = (size_t)4 * (BM * 64 + NPL * BN * 32);
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL>), lds); e != hipSuccess) return e;
+    constexpr size_t lds = (size_t)4 * (BM * (XH ? 32 : 64) + NPL * BN * 32);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH>), lds); e != hipSuccess) return e;
     const int rowsB = (int)(p.w_bytes / ((unsigned)p.K_pad * 2u));
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_b3d_kernel<BM, BN, WGM, WGN, NPL>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
+    hipLaunchKernelGGL((conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     return launch_splitk_reduce(p, (int)grid.y, st);
@@ -247,18 +277,33 @@ static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
 bool conv_b3d_eligible(const ConvParams& p) { return p.Cin % 16 == 0 && p.ktab != nullptr; }
 
 // p.w = the fragment-ordered planes (ConvParams::wb3r), p.w_bytes = bytes of one plane of one class; p.f16 == 1: the one-plane fp16 form
+// (with p.x_half: the pixel operand stored as half)
 hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st)
 {
     if (!conv_b3d_eligible(p)) return hipErrorInvalidValue;
+    if (p.f16 == 1 && p.x_half) {
+        switch (tile) {
+            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1, true>(p, st);
+            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1, true>(p, st);
+            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1, true>(p, st);
+            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1, true>(p, st);
+            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1, true>(p, st);
+            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1, true>(p, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     if (p.f16 == 1) {
         switch (tile) {
             case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1>(p, st);
             case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1>(p, st);
             case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1>(p, st);
             case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1>(p, st);
+            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1>(p, st);
+            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1>(p, st);
             default: return hipErrorInvalidValue;
         }
     }
+    if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // half storage exists in the fp16 form only
     switch (tile) {
         case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2>(p, st);          // 8 wavefronts, each 64 x 128: 160 KB of LDS, one block per CU
         case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2>(p, st);      // 8 wavefronts, each 32 x 128

@@ -131,3 +131,98 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Epilogue of the layers of an f16-mode plan that store / read HALF activations (conv_b3d.hip, NPL = 1; ConvParams::y_half,
+// res_half).  Same function as conv_epilogue -- split-K partials (fp32) or scale / shift -> + residual -> activation -> store -- with
+// the stored value rounded to half (RTNE) AFTER the whole epilogue, and a residual that may itself be stored as half.
+// A lane of the 32x32 accumulator holds one channel of 16 rows, its neighbour lane ^ 1 the next channel: for every pair of rows the
+// two lanes exchange one value each (one DPP row-xmask move), so that the even lane stores the channel pair of the first row and
+// the odd lane the pair of the second row as ONE dword -- half as many store instructions as a 2-byte store per value would need,
+// each covering whole 64-byte runs; the half residual is fetched the same way (one dword per lane and row pair) and exchanged back.
+// No dual output (the plan keeps such layers in fp32).
+template <int MI, int NI, int WGN>
+__device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
+                                                int lane, int py, int px, int HoWo)
+{
+    if (p.ksplit > 1 || (!p.y_half && !p.res_half)) {      // raw partial sums / an all-fp32 epilogue: the shared code
+        conv_epilogue<MI, NI, WGN, true>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+        return;
+    }
+    const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
+    const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+    auto pixel_of = [&](int m) -> unsigned {
+        if (m >= p.M) return OOB;
+        if (!p.deconv2x) return (unsigned)m;
+        int n, rem, oy, ox;
+        divmod_small(m, HoWo, inv_howo, n, rem);
+        divmod_small(rem, p.Wo, inv_wo, oy, ox);
+        const int yy = 2 * oy + py, xx = 2 * ox + px;
+        if (yy >= p.yH || xx >= p.yW) return OOB;
+        return (unsigned)((n * p.yH + yy) * p.yW + xx);
+    };
+    const bool odd = lane & 1;
+    auto swap1 = [](float v) -> float {      // the value of lane ^ 1
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+    };
+    auto h2f = [](unsigned bits16) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); };
+    auto f2h = [](float v) -> unsigned { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); };
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int co = n0 + (wn * NI + j) * 32 + (lane & 31);
+        const bool cok = co < p.Cout_store;      // Cout_store is a multiple of 4: a lane pair (even channel, odd channel) is valid together
+        const int cc = cok ? co : 0;
+        const float sc = p.scale[cc], sf = p.shift[cc];
+        const int cpair = co & ~1;               // first channel of this lane pair
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // rows of this lane: r(e) = rbase + i*32 + (e & 3) + 8 * (e >> 2); row pairs (e, e + 1), e even
+            float rv[16];
+            if (p.res) {
+                if (p.res_half) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        // even lane fetches {res[row e][c], res[row e][c+1]}, odd lane {res[row e+1][c-1], res[row e+1][c]}
+                        const unsigned px_ = pixel_of(rbase + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2));
+                        const unsigned d = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rr, (cok && px_ != OOB) ? (px_ * p.resCs + cpair) * 2u : OOB, 0, 0);
+                        const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)d, 0xB1, 0xF, 0xF, true);
+                        // even lane (channel c): row e = lo(own), row e+1 = lo(partner); odd lane (channel c+1): row e = hi(partner), row e+1 = hi(own)
+                        rv[e] = odd ? h2f(o >> 16) : h2f(d & 0xFFFFu);
+                        rv[e + 1] = odd ? h2f(d >> 16) : h2f(o & 0xFFFFu);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
+                        rv[e] = buf_load1(rr, (cok && px_ != OOB) ? (px_ * p.resCs + co) * 4u : OOB);
+                    }
+                }
+            }
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                v[e] = acc[i][j][e] * sc + sf + (p.res ? rv[e] : 0.f);
+                if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
+                else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+            }
+            if (p.y_half) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    // even lane writes row e: {own v[e], partner's v[e]}; odd lane writes row e+1: {partner's v[e+1], own v[e+1]}
+                    const float got = swap1(odd ? v[e] : v[e + 1]);
+                    const unsigned w = odd ? (f2h(got) | (f2h(v[e + 1]) << 16)) : (f2h(v[e]) | (f2h(got) << 16));
+                    const unsigned px_ = pixel_of(rbase + i * 32 + ((e + (odd ? 1 : 0)) & 3) + 8 * (e >> 2));
+                    __builtin_amdgcn_raw_buffer_store_b32((int)w, yr, (cok && px_ != OOB) ? (px_ * p.yCs + cpair) * 2u : OOB, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
+                    buf_store1(yr, (cok && px_ != OOB) ? (px_ * p.yCs + co) * 4u : OOB, v[e]);
+                }
+            }
+        }
+    }
+}

@@ -969,11 +969,23 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co);
     const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + co);
     f32x4 v = a * sc + sf;
-    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.resCs + co);
+    typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+    if (p.res && p.res_half) {
+        const f16x4s r = *reinterpret_cast<const f16x4s*>(reinterpret_cast<const _Float16*>(p.res) + pix * p.resCs + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    } else if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.resCs + co);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
         else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+    }
+    if (p.y_half) {      // half storage: rounded (RTNE) after the whole epilogue, like conv_epilogue_h
+        f16x4s h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+        *reinterpret_cast<f16x4s*>(reinterpret_cast<_Float16*>(p.y) + pix * p.yCs + co) = h;
+        return;
     }
     *reinterpret_cast<f32x4*>(p.y + pix * p.yCs + co) = v;
     if (p.y2) {
@@ -1072,6 +1084,7 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
 int conv_pick_tile(const ConvParams& p)
 {
     if (p.force_tile >= 0) return p.force_tile;
+    if (p.x_half || p.y_half || p.res_half) return p.Cout_store <= 64 ? CONV_TILE_B3D + 6 : CONV_TILE_B3D + 2;   // half views: conv_b3d.hip only
     const long classes = p.deconv2x ? 4 : 1;
     const int cs = p.Cout_store;
     if (cs <= 32) return p.f16 ? 3 : 4;                  // 128x32 (fp32) / 64x64 (fp16 path has no 32-wide tile)
@@ -1122,6 +1135,8 @@ static void tile_dims(int tile, int& bm, int& bn)
     if (tile == CONV_TILE_B3D || tile == CONV_TILE_B3D + 4) { bm = 256; bn = 256; return; }
     if (tile == CONV_TILE_B3D + 1 || tile == CONV_TILE_B3D + 5) { bm = 128; bn = 256; return; }
     if (tile == CONV_TILE_B3D + 2 || tile == CONV_TILE_B3D + 3) { bm = 128; bn = 128; return; }
+    if (tile == CONV_TILE_B3D + 6) { bm = 128; bn = 64; return; }
+    if (tile == CONV_TILE_B3D + 7) { bm = 256; bn = 128; return; }
     if (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 5) { static const int g[5] = {0, 1, 2, 3, 10}; tile = g[tile - CONV_TILE_B3]; }
     if (tile >= 31 && tile <= 35) { static const int g[5] = {3, 0, 2, 1, 4}; tile = g[tile - 31]; }   // deep-prefetch variants
     if (tile >= 20) tile = (tile == 23 || (tile >= 26 && tile != 29)) ? 3 : 0;
@@ -1199,14 +1214,16 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
-    if (p.force_tile >= CONV_TILE_B3D && p.force_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {
+    const int b3d_tile = (p.force_tile < 0 && (p.x_half || p.y_half || p.res_half)) ? conv_pick_tile(p) : p.force_tile;
+    if (b3d_tile >= CONV_TILE_B3D && b3d_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {
         // conv_b3d.hip: the fragment-ordered planes of conv_b3r (bf16x3) or its one-plane fp16 form, both operands by LDS-DMA
         if (!p.wb3r || p.f16 == 2) return hipErrorInvalidValue;
         ConvParams q = p;
         q.w = static_cast<const float*>(p.wb3r);
         if (!p.f16) { q.w_bytes = p.w_bytes / 2; q.f16 = 2; }
-        return launch_conv_b3d(q, p.force_tile, st);
+        return launch_conv_b3d(q, b3d_tile, st);
     }
+    if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // no other kernel reads or writes half views
     if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && p.f16 == 1) {
         // fp16-MFMA mode on the staging of conv_b3r.hip: one plane of half-rounded weights in MFMA fragment order
         if (!p.wb3r) return hipErrorInvalidValue;

@@ -61,6 +61,9 @@ struct ConvParams {
     const void* wb3r;      // null where wb3 is null (or ACCEL_B3R=0)
     const void* wub;       // conv_wino_b3.hip: U = G g G^T as three bf16 planes [plane][C/16][16][wino_rows][16]; null: not offered
     unsigned wub_bytes;
+    // half activation storage (f16-mode plans; conv_b3d.hip NPL = 1 only): the view is stored as half (2 bytes per element, channel
+    // strides in elements, x_bytes / y_bytes / res_bytes in bytes); values are rounded (RTNE) when stored, after the whole epilogue
+    int x_half, y_half, res_half;
 };
 
 hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st);
@@ -91,8 +94,9 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);
 #define CONV_TILE_B3D 82                 // conv_b3d.hip (both operands by LDS-DMA, pixels split after the fragment read): 82 = 256x256 / 4x2 wavefronts,
-                                         // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 86 = 256x256 / 8x1, 87 = 128x256 / 2x4
-#define CONV_TILE_B3D_N 6
+                                         // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 86 = 256x256 / 8x1, 87 = 128x256 / 2x4;
+                                         // fp16 form only: 88 = 128x64 / 4x1, 89 = 256x128 / 4x2
+#define CONV_TILE_B3D_N 8
 bool conv_b3d_eligible(const ConvParams& p);
 hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st);
 #define CONV_TILE_WS 60                  // weight-stationary streaming 1x1 (conv_1x1ws.hip)

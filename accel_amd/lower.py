@@ -53,10 +53,11 @@ class VBuf(object):
         self.id, self.Cs, self.H, self.W, self.space, self.N = bid, Cs, H, W, space, N
         self.first, self.last = None, None
         self.off = 0
+        self.esize = 4      # bytes per element: 4 = fp32; 2 = half (f16-mode plans with half activation storage, assign_storage)
 
     @property
     def nbytes(self):
-        return self.N * self.H * self.W * self.Cs * 4
+        return self.N * self.H * self.W * self.Cs * self.esize
 
     def touch(self, op_idx):
         if self.first is None:
@@ -86,14 +87,19 @@ class View(object):
         return self.buf.W
 
     def ref(self):
-        off = self.buf.off + self.coff * 4 + self.img0 * self.buf.H * self.buf.W * self.buf.Cs * 4
+        es = self.buf.esize
+        off = self.buf.off + self.coff * es + self.img0 * self.buf.H * self.buf.W * self.buf.Cs * es
         r = "%s:%d:%d:%d:%d:%d" % (self.buf.space, off, self.C, self.buf.Cs, self.buf.H, self.buf.W)
+        if es == 2:
+            return r + ":%d:h" % self.nimg                        # half storage: the tag follows an explicit batch size
         return r if self.nimg == 1 else r + ":%d" % self.nimg     # batch: images stacked pixel-major
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, fold_linear=True, feat_slot=None):
+    def __init__(self, sym, input_shapes, ncls=19, fold_linear=True, feat_slot=None, store_f16=False):
         self.sym = sym
+        self.store_f16 = bool(store_f16)      # f16-mode plans: arena buffers between capable convolutions are kept as half
+        self.half_bufs = []
         self.fold_linear = bool(fold_linear)
         # Ping-pong of the propagated feature (non-key graphs): a warp cannot run in place, so the plan either warps into
         # scratch and copies back (feat_slot None: two copies of 0.8 GB per call of 8 frames), or exists TWICE: variant 0
@@ -483,6 +489,7 @@ class Lowering(object):
         in_elems = ho * wo * kk * _r4(cin) if op == "DeformableConvolution" else hi * wi * cin
         w_elems = cout * cin * (16 if mode == "deconv2x" else kk)
         nbytes = 4.0 * (in_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
+        args["_elems"] = {"in": in_elems, "out": ho * wo * cout, "w": w_elems, "n": nb}
         self.emit("conv", args, [r for r in reads if r is not None], writes, flops=flops, nbytes=nbytes, nbytes_fixed=4.0 * w_elems, n=nb)
         self.absorbed.add(id(A))
         if feat_image is not None:
@@ -744,8 +751,51 @@ class Lowering(object):
         for h in self.heads:
             if h.op == "null":
                 self.outputs[h.name] = "input:" + h.name
+        if self.store_f16:
+            self.assign_storage()
         self.assign_offsets()
         return self
+
+    # ---- half activation storage (f16-mode plans, BASELINE config 5) ------------------------------------------------------------
+    @staticmethod
+    def half_capable(args):
+        """A convolution that can take half inputs / residuals and write half outputs: an f16-mode layer (Cin % 8 == 0 and more
+        than 4 output channels -- accel_hip.cpp finalize_conv) that conv_b3d.hip can run (Cin % 16 == 0: its K stage of 16 must
+        lie inside one tap), with a single output (the dual-output epilogue of the pre-activation nets stays fp32)."""
+        cin = _r4(int(args["cin"]))           # (mode=cols: the column buffer holds kh*kw taps of cin channels each, a 1x1 GEMM over them)
+        return cin % 16 == 0 and _r4(int(args["cout"])) > 4 and "out2" not in args and int(args.get("tile", -1)) < 0
+
+    def assign_storage(self):
+        """Specification of the half-storage mode (restated by oracle/graphs.py STORE_F16): an arena buffer is kept as HALF iff every
+        op that writes it is a half-capable convolution writing its (single) output there and every op that reads it is a
+        half-capable convolution reading it as data input or as residual.  Such a buffer's values are rounded to half (RTNE)
+        when they are stored, after the layer's whole epilogue (scale / shift, residual, activation); every reader sees the
+        rounded value.  For a consumer convolution that is what its loader would have rounded the fp32 value to anyway; the
+        residual reader is the one place where the function changes against fp32 storage.  Everything else -- persistent
+        buffers (images, `feat`, logits), concat buffers with ragged channel counts, inputs of pools / warps / the deformable
+        sampler / the narrow flow predictors -- stays fp32."""
+        uses = {}
+        for kind, args in self.ops:
+            for k, v in args.items():
+                if isinstance(v, View) and v.buf.space == "A":
+                    uses.setdefault(id(v.buf), [v.buf, []])[1].append((kind, k, args, v))
+        self.half_bufs = []
+        for buf, us in uses.values():
+            ok = buf.Cs % 8 == 0
+            for kind, k, args, v in us:
+                ok = ok and kind == "conv" and k in ("in", "out", "res") and self.half_capable(args) and v.coff % 8 == 0
+            if ok and any(k == "out" for _, k, _, _ in us):
+                buf.esize = 2
+                self.half_bufs.append(buf)
+        # algorithmic bytes of the convolutions that touch half buffers: every operand once, at its stored width
+        for kind, args in self.ops:
+            if kind != "conv" or "_elems" not in args:
+                continue
+            e = args["_elems"]
+            es = lambda key: (args[key].buf.esize if isinstance(args.get(key), View) else 4)
+            nbytes = e["n"] * (e["in"] * es("in") + e["out"] * es("out") + (e["out"] * es("res") if "res" in args else 0)
+                               + (e["out"] * 4 if "out2" in args else 0)) + 4.0 * e["w"]
+            args["bytes"] = "%.6g" % nbytes
 
     def assign_offsets(self):
         """Greedy first-fit arena packing over [first, last] op-index lifetimes (list order = execution order)."""
@@ -796,6 +846,8 @@ class Lowering(object):
         for kind, args in self.ops:
             toks = [kind]
             for k, v in args.items():
+                if k.startswith("_"):
+                    continue                    # lowering-internal bookkeeping
                 if isinstance(v, View):
                     v = v.ref()
                 elif isinstance(v, float):
@@ -843,6 +895,11 @@ def init_plan_text(name, d):
                                            d["from"], cin, _r4(cin), H, W, sfx, 2.0 * N * H * W * cin * cout)]) + "\n"
 
 
-def lower(sym, input_shapes, graph=True, conv_dtype="f32", fold_linear=True, feat_slot=None):
-    lw = Lowering(sym, input_shapes, fold_linear=fold_linear, feat_slot=feat_slot).run()
+def lower(sym, input_shapes, graph=True, conv_dtype="f32", fold_linear=True, feat_slot=None, store_f16=None):
+    """store_f16 (f16-mode plans only; default: on unless ACCEL_F16_STORAGE=0): activations between half-capable convolutions are
+    stored as half (Lowering.assign_storage)."""
+    import os
+    if store_f16 is None:
+        store_f16 = os.environ.get("ACCEL_F16_STORAGE", "1") != "0"
+    lw = Lowering(sym, input_shapes, fold_linear=fold_linear, feat_slot=feat_slot, store_f16=bool(store_f16) and conv_dtype == "f16").run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

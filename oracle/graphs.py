@@ -39,6 +39,20 @@ def _f16_layer(cin, cout):
     return ROUND_F16 and cin % 8 == 0 and cout > 4
 
 
+# Half activation STORAGE of the fp16 mode (accel_amd.lower.Lowering.assign_storage): the FUSED output of a convolution -- after
+# scale / shift, residual and activation -- is rounded to half when it is stored iff every op that reads it is a half-capable
+# convolution (as data input or as residual) and the layer itself is one; every reader then sees the rounded value.  The set of
+# such layers follows from the graph alone (tests/test_host_cpu.py pins it for the ResNet-50 / -101 trunks: every branch convolution
+# of res2-res5 except the res5 `branch2a` outputs, which the deformable sampler reads, and the last block, which is the propagated
+# feature; FlowNet conv3 / 4 / 5 / 6; the right head's fc6); the tests hand the names in.
+# STORE_F16: None, or the set of layer names (the convolution node's name) whose output is stored as half.
+STORE_F16 = None
+
+
+def _st(name, y):
+    return _h(y) if (ROUND_F16 and STORE_F16 and name in STORE_F16) else y
+
+
 def _dcn(name, stride_px, x, off, w, stride, pad, dilate, dg):
     if RECORD is not None:
         pts = O.deform_border_taps(x.shape[2], x.shape[3], off, w.shape[2:], stride, pad, dilate, BORDER_EPS)
@@ -87,12 +101,12 @@ def resnet_dcn_bottleneck(P, data, units, prefix, unit_namer, dcn_dg, offset_dil
             # stride 2 sits on the 1x1 convs of res3a / res4a (:647-652,:734-739); res5 keeps stride 1
             s = 2 if (first and stage in (3, 4)) else 1
             if first:
-                sc = _bn(P, p + "bn" + u + "_branch1",
-                         _conv(P, p + "res" + u + "_branch1", x, stride=s), EPS_DCN)
+                sc = _st(p + "res" + u + "_branch1", _bn(P, p + "bn" + u + "_branch1",
+                                                         _conv(P, p + "res" + u + "_branch1", x, stride=s), EPS_DCN))
             else:
                 sc = x
             y = _conv(P, p + "res" + u + "_branch2a", x, stride=s)
-            y = O.relu(_bn(P, p + "bn" + u + "_branch2a", y, EPS_DCN))
+            y = _st(p + "res" + u + "_branch2a", O.relu(_bn(P, p + "bn" + u + "_branch2a", y, EPS_DCN)))
             if stage == 5:
                 oname = p + "res" + u + "_branch2b_offset"
                 if offset_dilated:   # 72-ch, pad 2 dilate 2 (:514-515)
@@ -102,9 +116,9 @@ def resnet_dcn_bottleneck(P, data, units, prefix, unit_namer, dcn_dg, offset_dil
                 y = _dcn(p + "res" + u + "_branch2b", 16, y, off, P[p + "res" + u + "_branch2b_weight"], 1, 2, 2, dcn_dg)
             else:
                 y = _conv(P, p + "res" + u + "_branch2b", y, pad=1)
-            y = O.relu(_bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN))
+            y = _st(p + "res" + u + "_branch2b", O.relu(_bn(P, p + "bn" + u + "_branch2b", y, EPS_DCN)))
             y = _bn(P, p + "bn" + u + "_branch2c", _conv(P, p + "res" + u + "_branch2c", y), EPS_DCN)
-            x = O.relu(sc + y)
+            x = _st(p + "res" + u + "_branch2c", O.relu(sc + y))
     return x
 
 
@@ -180,13 +194,13 @@ def flownet(P, img_cur, img_ref):
     x = O.pool2d(data, "avg", 2, 2, 0, "full")
     r1 = lk(_conv(P, "flow_conv1", x, 2, 3, bias=True))
     r2 = lk(_conv(P, "conv2", r1, 2, 2, bias=True))
-    r3 = lk(_conv(P, "conv3", r2, 2, 2, bias=True))
+    r3 = _st("conv3", lk(_conv(P, "conv3", r2, 2, 2, bias=True)))
     r4 = lk(_conv(P, "conv3_1", r3, 1, 1, bias=True))
-    r5 = lk(_conv(P, "conv4", r4, 2, 1, bias=True))
+    r5 = _st("conv4", lk(_conv(P, "conv4", r4, 2, 1, bias=True)))
     r6 = lk(_conv(P, "conv4_1", r5, 1, 1, bias=True))
-    r7 = lk(_conv(P, "conv5", r6, 2, 1, bias=True))
+    r7 = _st("conv5", lk(_conv(P, "conv5", r6, 2, 1, bias=True)))
     r8 = lk(_conv(P, "conv5_1", r7, 1, 1, bias=True))
-    r9 = lk(_conv(P, "conv6", r8, 2, 1, bias=True))
+    r9 = _st("conv6", lk(_conv(P, "conv6", r8, 2, 1, bias=True)))
     r10 = lk(_conv(P, "conv6_1", r9, 1, 1, bias=True))
 
     def refine(feat_in, skip, pred_name, deconv_name, upflow_name):
@@ -214,7 +228,7 @@ def flownet(P, img_cur, img_ref):
 # --------------------------------------------------------------------------
 def head(P, feat, data_hw, prefix=""):
     p = prefix
-    x = O.relu(_conv(P, p + "fc6", feat, bias=True))
+    x = _st(p + "fc6", O.relu(_conv(P, p + "fc6", feat, bias=True)))
     s = _conv(P, p + "score", x, bias=True)
     ncls = s.shape[1]
     up = O.deconv2d(s, P[p + "upsampling_weight"], None, 16, 0, groups=ncls)
@@ -250,7 +264,7 @@ def cur_forward(P, version, data, data_key, feat_key):
         return out
     if version == "101":
         cur = resnet_dcn_101(P, data)
-        fused = _conv(P, "corr", np.concatenate([warped, cur], axis=1), bias=True)
+        fused = _st("correction", _conv(P, "corr", np.concatenate([warped, cur], axis=1), bias=True))
         out["croped_score_output"] = head(P, fused, hw)
         return out
     left = head(P, warped, hw)

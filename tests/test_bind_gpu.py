@@ -44,10 +44,14 @@ def test_bound_frames_give_the_same_logits_as_copied_frames(demo_cfg, monkeypatc
         wl.key.run()
         k0 = wl.model.read("logits", (wl.B, 19, H, W)).copy()
         keep = wl.dev_frames[0].clone()
+        import torch
+        torch.cuda.synchronize()
         wl.dev_frames[0].copy_(wl.dev_frames[2])
+        torch.cuda.synchronize()                    # torch's copy stream and the library's compute stream are not ordered by themselves
         wl.key.run()
         k2 = wl.model.read("logits", (wl.B, 19, H, W)).copy()
         wl.dev_frames[0].copy_(keep)
+        torch.cuda.synchronize()
         assert np.array_equal(k0, a[0]) and not np.array_equal(k2, k0)
         # a read of a bound input returns what the plans read (the caller's frame), not the model-owned copy left by an earlier write
         wl.model.write_device("data", wl.dev_frames[1].data_ptr(), wl.nbytes)
@@ -59,6 +63,7 @@ def test_bound_frames_give_the_same_logits_as_copied_frames(demo_cfg, monkeypatc
         assert nb == wl.nbytes
         torch_dst = __import__("accel_amd.dist", fromlist=["as_torch"]).as_torch(ptr, (wl.B, 3, H, W))
         torch_dst.copy_(wl.dev_frames[0])
+        __import__("torch").cuda.synchronize()      # the copy ran on torch's stream, the plan runs on the library's
         wl.key.run()
         assert np.array_equal(wl.model.read("logits", (wl.B, 19, H, W)), a[0]), "a write through accel_model_buffer's pointer was ignored"
         with pytest.raises(AccelError, match="not an image input"):
