@@ -831,10 +831,12 @@ static int finalize_op(accel_plan* p, Op& op)
     }
     case OP_DCN_COLS: {
         if ((rc = parse_buf(kv, "in", op.a)) || (rc = parse_buf(kv, "off", op.b)) || (rc = parse_buf(kv, "out", op.c))) return rc;
-        if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "off")) || (rc = resolve(p, op.c, "out"))) return rc;
+        // the column buffer may be a half view (f16-mode plans: its only reader, the GEMM, rounds the columns to half anyway)
+        if ((rc = resolve(p, op.a, "in")) || (rc = resolve(p, op.b, "off")) || (rc = resolve(p, op.c, "out", p->f16 == 1))) return rc;
         DcnColsParams& q = op.dcn;
         memset(&q, 0, sizeof q);
         q.x = op.a.ptr; q.off = op.b.ptr; q.col = op.c.ptr;
+        q.col_half = op.c.esize == 2;
         q.C = roundup(op.a.C, 4); q.xCs = op.a.Cs; q.offCs = op.b.Cs; q.colCs = op.c.Cs;
         q.H = op.a.H; q.W = op.a.W; q.Ho = op.c.H; q.Wo = op.c.W;
         kv_pair(kv, "k", q.kh, q.kw, 3, 3);

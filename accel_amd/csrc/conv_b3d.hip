@@ -46,19 +46,24 @@ __device__ __forceinline__ void split3_pair_d(float v0, float v1, unsigned& q0, 
 // NPL = 3: bf16x3; NPL = 1: the fp16-MFMA mode (pixels rounded to half after the fragment read, one plane of half-rounded weights);
 // XH (NPL = 1 only): the pixel operand is STORED as half (ConvParams::x_half): rows of 32 bytes per stage, the fragment is what the
 // DMA brought, no conversion at all; the epilogue of the NPL = 1 forms may read a half residual and write half (conv_epilogue_h)
-template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false>
+// KSUB: half steps (16 of K) per ring stage.  The bf16x3 form multiplies 6 * MI * NI matrix instructions per half step and wavefront, the
+// fp16 form MI * NI: with one half step per barrier the fp16 form spent its time at barriers (0.13-0.18 of the fp16 peak on the
+// deep-K layers of config 5), so its stages hold 2 or 4 half steps; NS = ring depth (3: two stages in flight, 4: three)
+template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false, int KSUB = 1, int NS = 4>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!XH || NPL == 1, "half pixel storage belongs to the fp16 form");
-    constexpr int NW = WGM * WGN, NS = 4;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    constexpr int NW = WGM * WGN;
     constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
-    constexpr int A_ROW = XH ? 32 : 64;                   // bytes of a pixel row per stage (16 of K)
-    constexpr int A_BYTES = BM * A_ROW, B_BYTES = NPL * BN * 32, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, NP = NA + NB;      // DMA pieces (1 KB = one wave instruction) per stage
+    constexpr int A_ROW = XH ? 32 : 64;                   // bytes of a pixel row per half step (16 of K)
+    constexpr int A_BYTES = BM * A_ROW, B_BYTES = NPL * BN * 32, SUB = A_BYTES + B_BYTES, STAGE = KSUB * SUB;
+    constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024, NP1 = NA + NB, NP = KSUB * NP1;      // DMA pieces (1 KB = one wave instruction) per stage
     static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "tiles are whole kilobytes");
-    // piece q of a stage belongs to wavefront q % NW: every wavefront issues LMAX or LMAX - 1 pieces per stage
-    constexpr int LMAX = (NP + NW - 1) / NW;
+    // piece q of a HALF STEP belongs to wavefront q % NW, the same for every half step of a stage (so the per-lane source offsets and
+    // the piece's kind do not depend on the half step): a wavefront issues KSUB * L1 or KSUB * (L1 - 1) pieces per stage
+    constexpr int L1 = (NP1 + NW - 1) / NW, LMAX = KSUB * L1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,17 +92,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     // fp32 pixel piece q (rows 16q ..): lane -> (row = lane >> 2, physical slot = lane & 3), fetches K quad slot ^ ((row >> 2) & 3)
     // half pixel piece q (rows 32q ..) and weight piece (plane q / (BN / 32), rows 32 (q % (BN / 32)) ..): lane -> (row = lane >> 1,
     // slot = lane & 1), fetches the 16-byte half slot ^ ((row >> 3) & 1)
-    bool pc_on[LMAX], pc_a[LMAX];
-    int pc_lds[LMAX], pc_iy0[LMAX], pc_ix0[LMAX];
-    unsigned pc_off[LMAX];
+    int pc_iy0[L1], pc_ix0[L1];
+    unsigned pc_off[L1];
 #pragma unroll
-    for (int t = 0; t < LMAX; ++t) {
-        const int q = wave + t * NW;
-        pc_on[t] = q < NP;
-        pc_a[t] = q < NA;
-        pc_lds[t] = q * 1024;           // pixel pieces first, then the weight planes: plane pl, row block rb at A_BYTES + (pl * (BN / 32) + rb) KB
+    for (int t = 0; t < L1; ++t) {
+        const int q = wave + t * NW;        // wave-uniform; pieces q >= NP1 do not exist (this wavefront then issues L1 - 1 per half step)
         pc_iy0[t] = pc_ix0[t] = 0;
-        if (pc_a[t]) {
+        pc_off[t] = 0;
+        if (q < NA) {
             const int r = XH ? q * 32 + (lane >> 1) : q * 16 + (lane >> 2);
             const int cbyte = XH ? (((lane & 1) ^ ((r >> 3) & 1)) * 16) : (((lane & 3) ^ ((r >> 2) & 3)) * 16);
             const int m = m0 + r;
@@ -108,48 +110,60 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
             pc_iy0[t] = ok ? oy * p.sh - ph : -(1 << 28);
             pc_ix0[t] = ox * p.sw - pw;
             pc_off[t] = (unsigned)((((n * p.H + pc_iy0[t]) * p.W + pc_ix0[t]) * p.xCs) * XB + cbyte);
-        } else {
+        } else if (q < NP1) {
             const int qb = q - NA, pl = qb / (BN / 32), rb = qb % (BN / 32);
             const int n = rb * 32 + (lane >> 1);
             const int h = (lane & 1) ^ ((n >> 3) & 1);
             pc_off[t] = (unsigned)pl * (unsigned)(2 * wplane) + (unsigned)((n0 + n) * 32 + h * 16);
         }
     }
-    const bool full = (NP % NW == 0) || wave < NP % NW;      // this wavefront issues LMAX pieces per stage (else LMAX - 1)
+    const bool full = (NP1 % NW == 0) || wave < NP1 % NW;      // this wavefront issues L1 pieces per half step (else L1 - 1)
     const unsigned hstep = (unsigned)rowsB * 32u;      // bytes of one half step of one plane
 
     const int KT_all = p.K_pad / 32;
     const int kt_begin = p.ksplit > 1 ? blockIdx.z * p.kt_per_split : 0;
     const int kt_end = p.ksplit > 1 ? min(KT_all, kt_begin + p.kt_per_split) : KT_all;
-    const int s_begin = 2 * kt_begin, ns = 2 * (kt_end - kt_begin);      // stages = half steps of 16
+    // stages of KSUB half steps; half steps past the end of the K range (the last stage of a range whose length is not a multiple of
+    // KSUB) multiply zeros: their tap entries are the table's slack (out of range).  A split-K range must therefore END on a stage
+    // boundary unless it is the last one (conv_plan_split rounds kt_per_split accordingly)
+    const int s_begin = 2 * kt_begin / KSUB, ns = (2 * (kt_end - kt_begin) + KSUB - 1) / KSUB;
     // the tap table through the CONSTANT address space: a scalar load (s_load_dwordx4) whatever the memory clobbers of the counted
     // waits below make the compiler assume -- as a vector load it would sit in the in-order vmcnt queue behind the DMAs and its
     // use would drain them
     typedef const int4 __attribute__((address_space(4)))* ktab_ptr;
     const ktab_ptr ktab = (ktab_ptr)(unsigned long long)(p.ktab + (p.deconv2x ? blockIdx.y * (p.K_pad / 4 + 48) : 0));
 
-    int4 tk_next = ktab[s_begin * 4];        // {dy, dx, byte offset, 0} of k = 16 s (Cin % 16 == 0: the 16 values share a tap)
-    auto issue = [&](int s /* global half-step index */, int slot) {
-        const int4 tk = tk_next;
-        tk_next = ktab[(s + 1) * 4];         // requested a stage ahead of its use
+    int4 tk_next[KSUB];                      // {dy, dx, byte offset, 0} of k = 16 h for the half steps h of a stage (Cin % 16 == 0: the 16 values share a tap)
+#pragma unroll
+    for (int u = 0; u < KSUB; ++u) tk_next[u] = ktab[(s_begin * KSUB + u) * 4];
+    auto issue = [&](int s /* global stage index */, int slot) {
         unsigned char* st = smem_d + slot * STAGE;
 #pragma unroll
-        for (int t = 0; t < LMAX; ++t) {
-            if (!pc_on[t]) continue;         // wave-uniform
-            if (pc_a[t]) {
-                const int iy = pc_iy0[t] + tk.x, ix = pc_ix0[t] + tk.y;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_d)(st + pc_lds[t]), 16, ok ? pc_off[t] + (unsigned)tk.z : OOB, 0, 0, 0);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wall, (lds_ptr_d)(st + pc_lds[t]), 16, pc_off[t], (unsigned)s * hstep, 0, 0);
+        for (int u = 0; u < KSUB; ++u) {
+            const int4 tk = tk_next[u];
+            tk_next[u] = ktab[((s + 1) * KSUB + u) * 4];      // requested a stage ahead of its use
+            const unsigned wsoff = (unsigned)(s * KSUB + u) * hstep;
+#pragma unroll
+            for (int t = 0; t < L1; ++t) {
+                const int q = wave + t * NW;      // wave-uniform
+                if (q >= NP1) continue;
+                unsigned char* dst = st + u * SUB + q * 1024;      // per half step: pixel pieces first, then the weight planes (plane pl, row block rb at A_BYTES + (pl * (BN / 32) + rb) KB)
+                if (q < NA) {
+                    const int iy = pc_iy0[t] + tk.x, ix = pc_ix0[t] + tk.y;
+                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_d)dst, 16, ok ? pc_off[t] + (unsigned)tk.z : OOB, 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wall, (lds_ptr_d)dst, 16, pc_off[t], wsoff, 0, 0);
+                }
             }
         }
     };
     // my pieces of the older stages have landed when at most `stages` newer stages of mine are outstanding
     auto wait_stages = [&](auto stages_c) {
         constexpr int n = decltype(stages_c)::value;
+        static_assert(n * LMAX < 64, "vmcnt is a 6-bit counter");
         if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n * LMAX) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n * (LMAX - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n * KSUB * (L1 - 1)) : "memory");
     };
 
     // ---- fragment addressing ----------------------------------------------------------------------------------------------------
@@ -182,8 +196,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     i32x4 fa[2][MI][NPL];
-    auto read_split_a = [&](int slot, int set) {
-        const unsigned char* st = smem_d + slot * STAGE;
+    auto read_split_a = [&](int slot, int sub, int set) {
+        const unsigned char* st = smem_d + slot * STAGE + sub * SUB;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if constexpr (XH) {
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
             }
         }
     };
-    auto mma = [&](int slot, int set) {
-        const unsigned char* st = smem_d + slot * STAGE;
+    auto mma = [&](int slot, int sub, int set) {
+        const unsigned char* st = smem_d + slot * STAGE + sub * SUB;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             i32x4 fb[NPL];
@@ -230,27 +244,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     };
 
     // ---- pipeline -----------------------------------------------------------------------------------------------------------------
-    // stages s_begin .. s_begin + ns - 1; stage t lives in ring slot t % 4.  Requests past the end are issued as well (branch-free
-    // body, exact counts): they fall on the slack entries of the tap table (zeros) and the slack rows of the weight planes.
+    // stages s_begin .. s_begin + ns - 1; stage t lives in ring slot t % NS, NS - 1 stages are requested ahead.  Requests past the end
+    // are issued as well (branch-free body, exact counts): they fall on the slack entries of the tap table (zeros) and the slack
+    // rows of the weight planes.  The fragments of the NEXT half step (the first one of stage k+1 at the end of stage k: the barrier
+    // of stage k publishes stage k+1 as well) are read and split / converted while the matrix instructions of the current one run.
     issue(s_begin, 0);
     issue(s_begin + 1, 1);
-    issue(s_begin + 2, 2);
-    wait_stages(std::integral_constant<int, 2>());
+    if constexpr (NS == 4) issue(s_begin + 2, 2);
+    wait_stages(std::integral_constant<int, NS - 2>());
     __builtin_amdgcn_s_barrier();
-    read_split_a(0, 0);
-    for (int k = 0; k < ns; k += 2) {
-        // even stage: fragments in set 0
-        wait_stages(std::integral_constant<int, 1>());                   // my pieces of stage k+1 have landed (k+2 may be in flight)
-        __builtin_amdgcn_s_barrier();                                    // stage k+1 complete for everyone; slot (k+3) % 4 no longer read
-        issue(s_begin + k + 3, (k + 3) & 3);
-        read_split_a((k + 1) & 3, 1);
-        mma(k & 3, 0);
-        // odd stage: fragments in set 1
-        wait_stages(std::integral_constant<int, 1>());
-        __builtin_amdgcn_s_barrier();
-        issue(s_begin + k + 4, (k + 4) & 3);
-        read_split_a((k + 2) & 3, 0);
-        mma((k + 1) & 3, 1);
+    read_split_a(0, 0, 0);
+    constexpr int UNR = (KSUB & 1) ? 2 : 1;      // stages per loop body: the fragment set alternates per half step
+    for (int k = 0; k < ns; k += UNR) {
+#pragma unroll
+        for (int r = 0; r < UNR; ++r) {
+            const int kk = k + r;
+            if (UNR == 2 && r == 1 && kk >= ns) break;
+            wait_stages(std::integral_constant<int, NS - 3>());              // my pieces of stage kk+1 have landed (NS = 4: kk+2 may be in flight)
+            __builtin_amdgcn_s_barrier();                                    // stage kk+1 complete for everyone; slot (kk-1) % NS no longer read
+            issue(s_begin + kk + NS - 1, (kk + NS - 1) % NS);
+#pragma unroll
+            for (int u = 0; u < KSUB; ++u) {
+                const int set = (r * KSUB + u) & 1;
+                if (u + 1 < KSUB) read_split_a(kk % NS, u + 1, set ^ 1);
+                else read_split_a((kk + 1) % NS, 0, set ^ 1);
+                mma(kk % NS, u, set);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may land after the block has given its LDS back
     if constexpr (NPL == 1) conv_epilogue_h<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
@@ -258,17 +278,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false>
+template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false, int KSUB = 1, int NS = 4>
 static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.Cout_store + BN - 1) / BN;
-    constexpr size_t lds = (size_t)4 * (BM * (XH ? 32 : 64) + NPL * BN * 32);
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH>), lds); e != hipSuccess) return e;
+    constexpr size_t lds = (size_t)NS * KSUB * (BM * (XH ? 32 : 64) + NPL * BN * 32);
+    static_assert(lds <= 163840, "160 KB of LDS per CU");
+    if (p.ksplit > 1 && (2 * p.kt_per_split) % KSUB) return hipErrorInvalidValue;      // a split-K range ends on a stage boundary (conv_plan_split)
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH, KSUB, NS>), lds); e != hipSuccess) return e;
     const int rowsB = (int)(p.w_bytes / ((unsigned)p.K_pad * 2u));
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
+    hipLaunchKernelGGL((conv_b3d_kernel<BM, BN, WGM, WGN, NPL, XH, KSUB, NS>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane, rowsB);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;
     return launch_splitk_reduce(p, (int)grid.y, st);
@@ -283,23 +305,25 @@ hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st)
     if (!conv_b3d_eligible(p)) return hipErrorInvalidValue;
     if (p.f16 == 1 && p.x_half) {
         switch (tile) {
-            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1, true>(p, st);
-            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1, true>(p, st);
-            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1, true>(p, st);
-            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1, true>(p, st);
-            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1, true>(p, st);
-            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1, true>(p, st);
+            // (stage = KSUB half steps, ring depth NS; LDS = NS * KSUB * (32 BM + 32 BN) bytes)
+            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1, true, 2, 4>(p, st);        // 128 KB, 16 matrix instructions per wavefront and barrier
+            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1, true, 4, 3>(p, st);    // 144 KB, 16
+            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1, true, 2, 3>(p, st);    // 48 KB: three blocks per CU, 8
+            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1, true, 2, 3>(p, st);    // 48 KB, 8
+            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1, true, 4, 3>(p, st);     // 72 KB: two blocks per CU, 8
+            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1, true, 4, 3>(p, st);    // 144 KB, 16
             default: return hipErrorInvalidValue;
         }
     }
     if (p.f16 == 1) {
         switch (tile) {
-            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1>(p, st);
-            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1>(p, st);
-            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1>(p, st);
-            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1>(p, st);
-            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1>(p, st);
-            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1>(p, st);
+            // fp32 pixels (64 bytes per row and half step), rounded to half after the fragment read
+            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 1, false, 2, 3>(p, st);       // 144 KB
+            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 1, false, 2, 4>(p, st);   // 128 KB
+            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 1, false, 2, 3>(p, st);   // 72 KB: two blocks per CU
+            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 1, false, 2, 3>(p, st);
+            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 1, false, 2, 3>(p, st);    // 60 KB
+            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 1, false, 2, 3>(p, st);   // 120 KB
             default: return hipErrorInvalidValue;
         }
     }

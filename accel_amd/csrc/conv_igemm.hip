@@ -1197,8 +1197,10 @@ size_t conv_plan_split(ConvParams& p)
     int ks = want < KT / min_steps ? want : KT / min_steps;
     if (ks < 2) return 0;
     p.kt_per_split = (KT + ks - 1) / ks;
+    // the fp16 form of conv_b3d.hip works in stages of up to four half steps (two K steps): a split-K range ends on a stage boundary
+    if (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N && p.f16 == 1) p.kt_per_split = (p.kt_per_split + 1) / 2 * 2;
     p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
-    if (p.ksplit < 2) { p.ksplit = 1; return 0; }
+    if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
     return (size_t)p.ksplit * classes * p.M * p.Cout_store * sizeof(float);
 }
 

@@ -143,6 +143,7 @@ struct DcnColsParams {
     int kh, kw, sh, sw, ph, pw, dh, dw;
     int dg;
     int N;                 // images (blockIdx.z), each H*W*xCs / Ho*Wo*offCs / Ho*Wo*colCs floats apart; 0 = 1
+    int col_half;          // the column buffer is stored as half (colCs in elements): values rounded (RTNE) when stored
 };
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st);
 

@@ -240,7 +240,13 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
         val.z = w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
         val.w = w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
     }
-    *reinterpret_cast<float4*>(p.col + zn * p.Ho * p.Wo * p.colCs + (size_t)pix * p.colCs + (size_t)tap * p.C + c4 * 4) = val;
+    const size_t at = zn * p.Ho * p.Wo * p.colCs + (size_t)pix * p.colCs + (size_t)tap * p.C + c4 * 4;
+    if (p.col_half) {
+        typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f16x4m*>(reinterpret_cast<_Float16*>(p.col) + at) = f16x4m{(_Float16)val.x, (_Float16)val.y, (_Float16)val.z, (_Float16)val.w};
+    } else {
+        *reinterpret_cast<float4*>(p.col + at) = val;
+    }
 }
 
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)

@@ -767,8 +767,9 @@ class Lowering(object):
 
     def assign_storage(self):
         """Specification of the half-storage mode (restated by oracle/graphs.py STORE_F16): an arena buffer is kept as HALF iff every
-        op that writes it is a half-capable convolution writing its (single) output there and every op that reads it is a
-        half-capable convolution reading it as data input or as residual.  Such a buffer's values are rounded to half (RTNE)
+        op that writes it is a half-capable convolution writing its (single) output there (or the deformable sampler writing the
+        column buffer of a deformable layer) and every op that reads it is a half-capable convolution reading it as data input or as
+        residual.  Such a buffer's values are rounded to half (RTNE)
         when they are stored, after the layer's whole epilogue (scale / shift, residual, activation); every reader sees the
         rounded value.  For a consumer convolution that is what its loader would have rounded the fp32 value to anyway; the
         residual reader is the one place where the function changes against fp32 storage.  Everything else -- persistent
@@ -783,12 +784,17 @@ class Lowering(object):
         for buf, us in uses.values():
             ok = buf.Cs % 8 == 0
             for kind, k, args, v in us:
+                if kind == "dcn_cols" and k == "out":
+                    continue        # the column buffer of a deformable layer: its only reader (checked like any reader) is the GEMM,
+                                    # which rounds the sampled columns to half in any case -- storing them rounded changes no value
                 ok = ok and kind == "conv" and k in ("in", "out", "res") and self.half_capable(args) and v.coff % 8 == 0
             if ok and any(k == "out" for _, k, _, _ in us):
                 buf.esize = 2
                 self.half_bufs.append(buf)
         # algorithmic bytes of the convolutions that touch half buffers: every operand once, at its stored width
         for kind, args in self.ops:
+            if kind == "dcn_cols" and args["out"].buf.esize == 2 and "bytes" in args:
+                args["bytes"] = "%.6g" % (0.75 * float(args["bytes"]))      # gathered reads at 4 bytes + the column store at 2
             if kind != "conv" or "_elems" not in args:
                 continue
             e = args["_elems"]

@@ -656,3 +656,52 @@ def test_flow_field_layers_stay_off_the_winograd_bf16_geometries(demo_cfg):
             (tagged if "wb3=0" in line.split() else free).add(name)
     assert {"conv3_1", "conv4_1", "conv5_1", "conv6_1", "flow_conv1", "Convolution5"} <= tagged
     assert all(not n.startswith("18_") for n in tagged) and any(n.startswith("18_") for n in free)
+
+
+@pytest.mark.parametrize("version", ["50", "101"])
+def test_half_storage_set_of_the_f16_mode(demo_cfg, version):
+    """f16-mode plans keep an arena buffer as half iff every writer is a half-capable convolution (or the deformable sampler writing
+    its column buffer) and every reader a half-capable convolution reading it as input or residual (lower.Lowering.assign_storage,
+    restated by oracle.graphs.STORE_F16).  Pinned here by NAME for the bottleneck trunks, written out independently of the rule:
+    every branch convolution of res2..res5 stores half, except the res5 `branch2a` outputs (the offset convolution's narrow
+    kernel and the deformable sampler read them as fp32) and the last block of a trunk whose output is a persistent buffer or
+    feeds a non-convolution; the stems, pools, FlowNet's concat buffers, the heads' score maps and every persistent buffer stay fp32."""
+    import re
+    got = {}
+    for key in (True, False):
+        text, lw = _plan(version, key, H=256, W=512, conv_dtype="f16", store_f16=True, fold_linear=False)
+        for kind, a in lw.ops:
+            if kind == "conv":
+                got[a["name"]] = (a["in"].buf.esize, a["out"].buf.esize, a["res"].buf.esize if "res" in a else None)
+            elif kind == "dcn_cols":
+                got[a["name"]] = (a["in"].buf.esize, a["out"].buf.esize, None)
+            else:
+                for k, v in a.items():
+                    assert not hasattr(v, "buf") or v.buf.esize == 4, "only convolutions and column buffers touch half views: %s %s" % (kind, k)
+        assert "A" not in [b.space for b in lw.half_bufs if b.space != "A"] and all(b.space == "A" for b in lw.half_bufs)
+    trunks = [""] + (["50_"] if version == "50" else [])
+    for name, (xin, out, res) in got.items():
+        m = re.match(r"^(50_)?res(\d)(\w+?)_branch(1|2a|2b|2c)(_offset|_cols)?$", name)
+        if not m or (m.group(1) or "") not in trunks:
+            continue
+        stage, blk, br, sfx = int(m.group(2)), m.group(3), m.group(4), m.group(5)
+        if sfx == "_offset":
+            assert (xin, out) == (4, 4), name                  # reads the fp32 branch2a output, writes the fp32 offsets
+        elif sfx == "_cols":
+            assert (xin, out) == (4, 2), name                  # the sampler reads fp32, the column buffer is half
+        elif stage == 5 and br == "2a":
+            assert out == 4, name
+        elif stage == 5 and br == "2c" and blk == "c" and not (m.group(1) or ""):
+            assert out == 4 and res == 2, name                 # res5c of the key trunk writes the persistent feature
+        else:
+            assert out == 2, name
+        if br == "2c":
+            assert res == 2, name                              # the shortcut (branch1 output or the previous block) is half
+    for name in ("conv1", "flow_conv1", "conv2", "score", "Convolution1", "deconv5"):
+        if name in got:
+            assert got[name][1] == 4, name
+    assert got["conv3"][1] == 2 and got["conv3_1"][:2] == (2, 4)      # FlowNet: conv3 -> conv3_1 is a plain chain, conv3_1 writes into a concat
+    # with storage off nothing is half, and fp32 plans never are
+    for kw in (dict(conv_dtype="f16", store_f16=False), dict(conv_dtype="f32", store_f16=True)):
+        text, lw = _plan(version, False, H=256, W=512, **kw)
+        assert ":h " not in text and not lw.half_bufs
