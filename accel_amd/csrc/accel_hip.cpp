@@ -693,7 +693,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     {
         // direct stem kernel (7x7 / stride 2 / pad 3, 3-channel image, 64 output channels): per-lane weight arrangement
         const char* se = getenv("ACCEL_STEM");
-        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_STEM;
+        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_STEM || c.force_tile == CONV_TILE_STEM_B3;
         c.Cout_store = cout_store;
         c.res = op.d.set ? op.d.ptr : nullptr;
         if (want && !cols && cin == 3 && cout == 64 && conv_stem_eligible(c)) {
@@ -702,7 +702,17 @@ static int finalize_conv(accel_plan* p, Op& op)
             void* dsw = nullptr;
             if ((rc = dev_upload(p, ws.data(), ws.size() * sizeof(float), &dsw))) return rc;
             c.wstem = static_cast<const float*>(dsw);
-        } else if (c.force_tile == CONV_TILE_STEM) {
+            const char* be_ = getenv("ACCEL_BF16X3");
+            const char* sb_ = getenv("ACCEL_STEM_B3");
+            if ((!(be_ && be_[0] == '0') && !(sb_ && sb_[0] == '0')) || c.force_tile == CONV_TILE_STEM_B3) {
+                // the same layer for the bf16 matrix cores: three exact bf16 planes in MFMA fragment order (launch geometry 51)
+                std::vector<unsigned short> wb;
+                conv_stem_b3_pack(w->data.data(), cout, wb);
+                void* dsb = nullptr;
+                if ((rc = dev_upload(p, wb.data(), wb.size() * sizeof(unsigned short), &dsb))) return rc;
+                c.wstemb = dsb;
+            }
+        } else if (c.force_tile == CONV_TILE_STEM || c.force_tile == CONV_TILE_STEM_B3) {
             return fail(ACCEL_ERR_ARG, "conv %s: the stem kernel takes 7x7 / stride 2 / pad 3 layers on 3-channel images with 64 "
                                        "output channels only", op.name.c_str());
         }
@@ -1144,6 +1154,7 @@ static int autotune_plan(accel_plan* p)
                 }
             }
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
+            if (c.wstemb && !c.f16) cs.push_back({CONV_TILE_STEM_B3, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
@@ -1217,7 +1228,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0) + 2048 * c.x_half + 4096 * c.y_half + 8192 * c.res_half, c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0) + 2048 * c.x_half + 4096 * c.y_half + 8192 * c.res_half + 16384 * (c.wstemb ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it != g_tune_cache.end()) {

@@ -1118,7 +1118,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_WS ||
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS ||
            (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5) ||
            (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N);
 }
@@ -1152,7 +1152,7 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
-    if (tile == CONV_TILE_STEM || tile == CONV_TILE_WS) return 0;
+    if (tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS) return 0;
     if (tile == CONV_TILE_WINO) {
         // Winograd blocks own 64 tiles (256 pixels) x 64 channels; the K loop runs in steps of 8 channels, unrolled by 2.
         // Splitting it over blockIdx.y leaves raw partial OUTPUTS (the output transform is linear) that the ordinary
@@ -1215,6 +1215,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WINO_B3U) return launch_conv_wino_b3(p, st, true);
     if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(p, st);
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
+    if (p.force_tile == CONV_TILE_STEM_B3) return launch_conv_stem_b3(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
     const int b3d_tile = (p.force_tile < 0 && (p.x_half || p.y_half || p.res_half)) ? conv_pick_tile(p) : p.force_tile;
     if (b3d_tile >= CONV_TILE_B3D && b3d_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {

@@ -51,6 +51,7 @@ struct ConvParams {
     int wino_bhs;          // geometry 42: log2 of the tile-block height (3 / 2 / 1 = 8x8 / 4x16 / 2x32 tiles), filled by the launcher
     // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
     const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
+    const void* wstemb;    // the same layer on the bf16 matrix cores (conv_stem_b3.hip, tile id 51): three bf16 planes in fragment order; null: not offered
     // weight-stationary streaming 1x1 variant (conv_1x1ws.hip, tile id 60): weights as the LDS image per column group
     // bf16x3 variant of an fp32 layer (launch geometries 70-74): the weights once more, split into three bf16 planes
     const void* wb3;       // null: Cin % 8 != 0, narrow output, or ACCEL_BF16X3=0
@@ -86,6 +87,10 @@ long conv_wino_b3s_blocks(const ConvParams& p, int* bhs);
 hipError_t launch_conv_wino_b3s(const ConvParams& p, hipStream_t st);
 hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st);   // sums ws[split][class][M][Cout_store] + epilogue
 #define CONV_TILE_STEM 50
+#define CONV_TILE_STEM_B3 51      // the stem on the bf16 matrix cores, three exact bf16 terms per operand (conv_stem_b3.hip)
+bool conv_stem_b3_eligible(const ConvParams& p);
+void conv_stem_b3_pack(const float* w, int Cout, std::vector<unsigned short>& out);
+hipError_t launch_conv_stem_b3(const ConvParams& p, hipStream_t st);
 bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();

@@ -353,23 +353,41 @@ def test_conv2d_winograd_rejects_other_geometries(ctx):
         ctx.conv2d(x, w, None, 1, 1, 1, tile=21)                          # timing-only ablation id: diagnostics build only
 
 
-# ---- direct 7x7/2 stem kernel (launch geometry id 50, conv_stem.hip) -----------------------------------------------------
-@pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 50, 70), (1, 16, 128), (3, 37, 131), (1, 128, 256)])
-def test_conv2d_stem_kernel_matches_oracle(ctx, N, H, W):
+# ---- direct 7x7/2 stem kernel (launch geometry id 50, conv_stem.hip) and the same layer on the bf16 matrix cores, three exact bf16
+# ---- terms per operand (id 51, conv_stem_b3.hip) ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [50, 51])
+@pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 50, 70), (1, 16, 128), (3, 37, 131), (1, 128, 256), (3, 250, 518)])
+def test_conv2d_stem_kernel_matches_oracle(ctx, tile, N, H, W):
+    """one tile, ragged tiles in both directions, and (last case: 3 x 125 x 259 outputs = 240 tiles of 8 x 64) more tiles than a
+    quarter of the persistent blocks so that blocks walk on and both window stages get reused"""
     x, w, b = rnd(80, N, 3, H, W, scale=50.0), rnd(81, 64, 3, 7, 7, scale=(2.0 / 147) ** 0.5 / 50.0), rnd(82, 64)
     ref = O.conv2d(x, w, b, 2, 3, 1)
-    close(ctx.conv2d(x, w, b, 2, 3, 1, tile=50), ref)
+    close(ctx.conv2d(x, w, b, 2, 3, 1, tile=tile), ref)
     scale, shift = rnd(83, 64), rnd(84, 64)
     ref2 = O.relu(O.conv2d(x, w, None, 2, 3, 1) * scale[None, :, None, None] + shift[None, :, None, None])
-    close(ctx.conv2d(x, w, None, 2, 3, 1, scale=scale, shift=shift, act=1, tile=50), ref2)
+    close(ctx.conv2d(x, w, None, 2, 3, 1, scale=scale, shift=shift, act=1, tile=tile), ref2)
 
 
-def test_conv2d_stem_kernel_rejects_other_layers(ctx):
+def test_conv2d_stem_bf16x3_error_is_of_the_order_of_the_fp32_kernels(ctx):
+    """against a float64 convolution: the three-term split adds nothing measurable to the fp32 accumulation noise"""
+    import torch
+    import torch.nn.functional as F
+    x, w = rnd(90, 2, 3, 120, 200, scale=50.0), rnd(91, 64, 3, 7, 7, scale=0.002)
+    truth = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=2, padding=3).numpy()
+    sc = max(1.0, float(np.abs(truth).max()))
+    e50 = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=50) - truth).max()) / sc
+    e51 = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=51) - truth).max()) / sc
+    print("stem, max error / output scale vs float64: fp32 MFMA %.2e, bf16x3 %.2e" % (e50, e51))
+    assert e51 <= 3e-6 and e51 <= 4 * e50 + 2e-7
+
+
+@pytest.mark.parametrize("tile", [50, 51])
+def test_conv2d_stem_kernel_rejects_other_layers(ctx, tile):
     from accel_amd.runtime import AccelError
     with pytest.raises(AccelError, match="stem kernel"):
-        ctx.conv2d(rnd(85, 1, 6, 32, 32), rnd(86, 64, 6, 7, 7), None, 2, 3, 1, tile=50)       # FlowNet's 6-channel stem
+        ctx.conv2d(rnd(85, 1, 6, 32, 32), rnd(86, 64, 6, 7, 7), None, 2, 3, 1, tile=tile)       # FlowNet's 6-channel stem
     with pytest.raises(AccelError, match="stem kernel"):
-        ctx.conv2d(rnd(87, 1, 3, 32, 32), rnd(88, 32, 3, 7, 7), None, 2, 3, 1, tile=50)       # 32 output channels
+        ctx.conv2d(rnd(87, 1, 3, 32, 32), rnd(88, 32, 3, 7, 7), None, 2, 3, 1, tile=tile)       # 32 output channels
 
 
 # ---- weight-stationary streaming 1x1 kernel (launch geometry id 60, conv_1x1ws.hip) --------------------------------------
