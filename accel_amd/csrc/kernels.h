@@ -172,6 +172,7 @@ hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st);
 hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st);
 hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st);
+hipError_t launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st);      // flat device-to-device copy (one kernel, 16-byte accesses)
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st);   // Cout_store == 4, plain conv, no dual output
 hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,
                                     float* z, int zCs, int ncls, int npix, hipStream_t st);

@@ -3,6 +3,7 @@
 // channel axis (or along x for the NCHW boundary tensors), grid-stride free
 // (one element quad per thread, grids >> 256 CUs).
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <math.h>
 #include "kernels.h"
 
@@ -517,6 +518,33 @@ hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int 
     const int C4 = (C + 3) / 4;
     const long total = (long)HW * C4;
     hipLaunchKernelGGL(copy_view_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sCs, dst, dCs, C4, total);
+    return hipGetLastError();
+}
+
+// Flat device-to-device copy of a persistent buffer (accel_model_write with a source that already lives in HBM: the executor's
+// copy-in of a resident frame).  hipMemcpyAsync(DeviceToDevice) runs as a runtime blit kernel in ~25 MB pieces at 1.2 TB/s
+// (profiles/r04_rocprof_summary.md: __amd_rocclr_copyBuffer, 20 us per piece); this is one launch of 16-byte accesses, four in flight
+// per thread, grid sized to the chip.
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + 256 * k < n16) v[k] = src[i + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + 256 * k < n16) dst[i + 256 * k] = v[k];
+    }
+}
+
+hipError_t launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st)
+{
+    if (bytes % 16 || (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16)
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    const size_t n16 = bytes / 16;
+    const size_t blocks = (n16 + 1023) / 1024;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                       static_cast<const float4*>(src), static_cast<float4*>(dst), n16);
     return hipGetLastError();
 }
 

@@ -150,6 +150,7 @@ PIPES = {"conv_igemm_b3_kernel": (6.0, BF16_PEAK_TFLOPS, "bf16 MFMA, six product
          "conv_wino_f32_kernel": (1.0 / 2.25, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA, Winograd F(2x2,3x3): 16/36 of the direct multiply-adds"),
          "conv_igemm_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"), "conv_stem_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"),
          "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (weight-stationary streaming 1x1)"),
+         "conv_stem_b3_kernel": (6.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "bf16 MFMA, the 7x7/2 stems as six bf16 products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic)"),
          "conv_f16_kernel": (1.0, BF16_PEAK_TFLOPS, "fp16 MFMA, ONE half product per multiply-add (f16-mode layer on any geometry: conv_igemm_f16 / conv_b3r<NPL=1> / conv_b3d<NPL=1>)")}
 
 
@@ -168,6 +169,8 @@ def conv_family(op, dtype="f32"):
         return "conv_wino_f32_kernel"
     if t == 50:
         return "conv_stem_f32_kernel"
+    if t == 51:
+        return "conv_stem_b3_kernel"
     if t == 60:
         return "conv1x1_ws_kernel"
     if mode == 2 or 70 <= t <= 87:

@@ -37,6 +37,7 @@ def test_families_of_the_other_geometries():
     fam = lambda t, **k: bench.conv_family(op(t, **k), "f32")
     assert fam(40) == "conv_wino_f32_kernel" and fam(41) == fam(42) == fam(43) == "conv_wino_b3_kernel"
     assert fam(50) == "conv_stem_f32_kernel" and fam(60) == "conv1x1_ws_kernel" and fam(10) == "conv_igemm_f32_kernel"
+    assert fam(51) == "conv_stem_b3_kernel" and bench.PIPES["conv_stem_b3_kernel"][0] == pytest.approx(6 * 176 / 147)
     assert fam(9, narrow=1) == "conv_narrow_kernel"
     assert bench.conv_family(op(3, mode=2), "bf16x3") == "conv_igemm_b3_kernel"        # bf16x3 plan option on a classic geometry id
 
