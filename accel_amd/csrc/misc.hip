@@ -250,8 +250,92 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
     }
 }
 
+// The same function with ONE thread per (pixel, channel quad) walking all kh*kw = 9 taps: the nine offset pairs are fetched first,
+// then the 36 corner fetches of the nine taps are in flight together, then nine stores -- the one-tap-per-thread form above has two
+// dependent memory round trips (offset, corners) per 16 bytes written and reached 2.1 TB/s of column writes (round-4 profile: 559-574
+// us for the 1.2 GB column buffer of a res5 layer at 8 clips); same arithmetic per value, same results bit for bit.
+template <int TPT, bool NT = false>      // taps per thread: 9 (all of them) or 3 (one kernel row; blockIdx.y = the row); NT: streaming stores
+__global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
+{
+    const int C4 = p.C / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.Ho * p.Wo * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int pix = (int)(idx / C4);
+    const int t0 = TPT * blockIdx.y;
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    const int cpg = p.C / p.dg;
+    const int g = (c4 * 4) / cpg;
+    const size_t zn = blockIdx.z;
+    const float* offp = p.off + zn * p.Ho * p.Wo * p.offCs + (size_t)pix * p.offCs + g * 18;
+    float2 o[TPT];
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) o[t] = *reinterpret_cast<const float2*>(offp + 2 * (t0 + t));
+    const int h_in = oy * p.sh - p.ph, w_in = ox * p.sw - p.pw;
+    const float* b = p.x + zn * p.H * p.W * p.xCs + c4 * 4;
+    float4 v1[TPT], v2[TPT], v3[TPT], v4[TPT];
+    float w1[TPT], w2[TPT], w3[TPT], w4[TPT];
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+        const int i = (t0 + t) / 3, j = (t0 + t) - 3 * i;
+        const float oh = o[t].x, ow = o[t].y;
+        const float h_im = (float)(h_in + i * p.dh) + oh;
+        const float w_im = (float)(w_in + j * p.dw) + ow;
+        const bool in = h_im >= 0 && w_im >= 0 && h_im < p.H && w_im < p.W;
+        float h = (float)(i * p.dh) + oh, w = (float)(j * p.dw) + ow;
+        const int height = p.H - h_in, width = p.W - w_in;
+        int h_low = (int)floorf(h), w_low = (int)floorf(w);
+        int h_high, w_high;
+        if (h_low >= height - 1) { h_high = h_low = height - 1; h = (float)h_low; } else h_high = h_low + 1;
+        if (w_low >= width - 1) { w_high = w_low = width - 1; w = (float)w_low; } else w_high = w_low + 1;
+        const float lh = h - h_low, lw = w - w_low;
+        const float hh = 1 - lh, hw = 1 - lw;
+        const int y0 = min(max(h_in + h_low, 0), p.H - 1), y1 = min(max(h_in + h_high, 0), p.H - 1);
+        const int x0 = min(max(w_in + w_low, 0), p.W - 1), x1 = min(max(w_in + w_high, 0), p.W - 1);
+        v1[t] = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x0) * p.xCs);
+        v2[t] = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x1) * p.xCs);
+        v3[t] = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x0) * p.xCs);
+        v4[t] = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x1) * p.xCs);
+        // a sample outside the image contributes zero (DCN v1): zero weights instead of a branch around the fetches
+        w1[t] = in ? hh * hw : 0.f; w2[t] = in ? hh * lw : 0.f; w3[t] = in ? lh * hw : 0.f; w4[t] = in ? lh * lw : 0.f;
+    }
+    const size_t at0 = zn * p.Ho * p.Wo * p.colCs + (size_t)pix * p.colCs + c4 * 4;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
+        float4 val;
+        val.x = w1[t] * v1[t].x + w2[t] * v2[t].x + w3[t] * v3[t].x + w4[t] * v4[t].x;
+        val.y = w1[t] * v1[t].y + w2[t] * v2[t].y + w3[t] * v3[t].y + w4[t] * v4[t].y;
+        val.z = w1[t] * v1[t].z + w2[t] * v2[t].z + w3[t] * v3[t].z + w4[t] * v4[t].z;
+        val.w = w1[t] * v1[t].w + w2[t] * v2[t].w + w3[t] * v3[t].w + w4[t] * v4[t].w;
+        const size_t at = at0 + (size_t)(t0 + t) * p.C;
+        if (p.col_half) {
+            typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f16x4m*>(reinterpret_cast<_Float16*>(p.col) + at) = f16x4m{(_Float16)val.x, (_Float16)val.y, (_Float16)val.z, (_Float16)val.w};
+        } else if (NT) {
+            typedef float f32x4m __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f32x4m{val.x, val.y, val.z, val.w}, reinterpret_cast<f32x4m*>(p.col + at));
+        } else {
+            *reinterpret_cast<float4*>(p.col + at) = val;
+        }
+    }
+}
+
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)
 {
+    const char* one = getenv("ACCEL_DCN_ONE_TAP");       // A/B switch: the one-tap-per-thread kernel
+    if (p.kh == 3 && p.kw == 3 && !(one && one[0] == '1')) {
+        // measured (scripts/microbench/dcn_time.py, res5 of the key plan at 8 clips / of the ResNet-18 branch / at one clip): one tap per
+        // thread 511 / 137 / 80 us, three taps (one kernel row) 431 / 82 / 55, nine 464 / 99 / 56, three with streaming stores 389 / 80 / 55:
+        // a column buffer beyond the 256 MB Infinity Cache is written past the caches, a smaller one stays cached for the GEMM behind it
+        const char* tp = getenv("ACCEL_DCN_TAPS");      // diagnostics: '9' = all taps per thread, 'n' / 'c' = force streaming / cached stores
+        const long total = (long)p.Ho * p.Wo * (p.C / 4);
+        const size_t col_bytes = (size_t)(p.N > 0 ? p.N : 1) * p.Ho * p.Wo * p.colCs * (p.col_half ? 2 : 4);
+        const bool nt = tp && tp[0] == 'n' ? true : tp && tp[0] == 'c' ? false : col_bytes > ((size_t)256 << 20);
+        if (tp && tp[0] == '9') hipLaunchKernelGGL(dcn_cols9_kernel<9>, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
+        else if (nt) hipLaunchKernelGGL((dcn_cols9_kernel<3, true>), dim3(cdiv(total, 256), 3, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dcn_cols9_kernel<3>, dim3(cdiv(total, 256), 3, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     const long total = (long)p.Ho * p.Wo * p.kh * p.kw * (p.C / 4);
     hipLaunchKernelGGL(dcn_cols_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
     return hipGetLastError();
