@@ -109,7 +109,12 @@ for (name, cin, cout, H, W, k, s, p, d, res, mode) in SHAPES:
             t += " res=A:%d:%d:%d:%d:%d" % (o_r, cout, kp, Ho, Wo)
         t += "\n"
         plan = m.add_plan("b", t)
-        m.write("x", np.maximum(rng.standard_normal((cin, H, W)), 0).astype(np.float32))
+        xin = np.maximum(rng.standard_normal((cin, H, W)), 0).astype(np.float32)
+        if __import__('os').environ.get("XDATA") == "zero":      # power / clock experiment: the same launch on all-zero pixels
+            xin[:] = 0
+        elif __import__('os').environ.get("XDATA") == "dense":   # no ReLU zeros: every operand bit toggles
+            xin = rng.standard_normal((cin, H, W)).astype(np.float32)
+        m.write("x", xin)
         m.write("r", rng.standard_normal((cout, Ho, Wo)).astype(np.float32))
         plan.finalize()
         for _ in range(60): plan.run()      # warm the clocks: short isolated launches under-clock
