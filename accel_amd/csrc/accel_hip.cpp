@@ -153,6 +153,18 @@ struct accel_plan {
     bool allow_graph = true;
     bool allow_tune = true;
     int f16 = 0;                    // option dtype=f16: convolutions on the fp16 matrix cores; dtype=bf16x3: 2 (kernels.h)
+    // fp32 layers on the matrix cores: split = 1 (default) the fp16x2 form (two half terms per operand, three products), 0 the
+    // bf16x3 form (three bf16 terms, six products) -- plan option split=b3|h2, ACCEL_SPLIT=b3|h2.  The fp16x2 form centres every
+    // convolution's pixels in the half range by a power of two kept in `range` (four words per op: {s, 1/s, probed max bits, flags});
+    // a PROBED run (the first run of the plan and every recal_every-th after it) measures the input range of each such
+    // convolution right before it runs and sets the scale on the device (misc.hip range_set_kernel); range_flag is the sticky
+    // host-visible word a probe raises when the range had outgrown the scale.
+    int split = 1;
+    float* range = nullptr;
+    unsigned* range_flag = nullptr;       // host-mapped
+    unsigned* range_flag_dev = nullptr;
+    int n_h2 = 0;
+    long runs = 0, recal_every = 256;
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of the plan (stream-ordered)
     float* ws = nullptr;
     std::vector<std::string> pbuf_reads, pbuf_writes;   // persistent buffers the ops read / write (derived-buffer tracking)
@@ -270,6 +282,7 @@ static int parse_plan(accel_plan* p, const char* text)
             if (kv_has(kv, "graph")) p->allow_graph = kv_int(kv, "graph", 1) != 0;
             if (kv_has(kv, "tune")) p->allow_tune = kv_int(kv, "tune", 1) != 0;
             if (kv_has(kv, "dtype")) p->f16 = kv_str(kv, "dtype") == "f16" ? 1 : kv_str(kv, "dtype") == "bf16x3" ? 2 : 0;
+            if (kv_has(kv, "split")) p->split = kv_str(kv, "split") == "b3" ? 0 : 1;
             continue;
         }
         if (kind == "meta") {
@@ -393,6 +406,33 @@ static void pack_bf16x3r(const std::vector<float>& packed, int classes, int rows
                     float t; memcpy(&t, &u, 4);
                     r -= t;
                 }
+            }
+}
+
+// fp16x2 form of the same fragment-ordered planes (ConvParams::wh2r): every weight as hi + lo, two half terms of w * 2^q[row], the
+// exponent q[row] chosen so that the largest weight of the output channel (over all parity classes) lands in [2^14, 2^15) -- the
+// top of the half range, where lo keeps its full 11 bits for every weight down to 2^-16 of the channel's largest (below that the
+// absolute error is 2^-25, i.e. 2^-39 of the largest).  qexp receives q per row; the epilogue scale is multiplied by 2^-q (exact).
+static void pack_h2r(const std::vector<float>& packed, int classes, int rows, int K_pad, std::vector<uint16_t>& out, size_t plane, std::vector<int>& qexp)
+{
+    const int steps = K_pad / 32;
+    out.assign(2 * plane, 0);
+    qexp.assign(rows, 0);
+    for (int n = 0; n < rows; ++n) {
+        float amax = 0.f;
+        for (int c = 0; c < classes; ++c)
+            for (int k = 0; k < K_pad; ++k) amax = std::max(amax, std::fabs(packed[((size_t)c * rows + n) * K_pad + k]));
+        if (amax > 0.f && std::isfinite(amax)) { int e; std::frexp(amax, &e); qexp[n] = 15 - e; }
+    }
+    for (int c = 0; c < classes; ++c)
+        for (int n = 0; n < rows; ++n)
+            for (int k = 0; k < K_pad; ++k) {
+                const float v = std::ldexp(packed[((size_t)c * rows + n) * K_pad + k], qexp[n]);
+                const int ks = k / 32, kb = (k >> 4) & 1, kk = k & 15;
+                const size_t dst = ((((size_t)c * steps + ks) * 2 + kb) * rows + n) * 16 + kk;
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                memcpy(&out[dst], &hi, 2);
+                memcpy(&out[plane + dst], &lo, 2);
             }
 }
 
@@ -577,6 +617,24 @@ static int finalize_conv(accel_plan* p, Op& op)
         (rc = dev_upload(p, shift.data(), rows * sizeof(float), &db))) return rc;
     c.scale = static_cast<const float*>(ds);
     c.shift = static_cast<const float*>(db);
+    {
+        const char* sp = getenv("ACCEL_SPLIT");
+        const bool h2 = sp ? !strcmp(sp, "h2") : p->split == 1;
+        if (c.wb3r && !c.f16 && h2) {
+            std::vector<uint16_t> ph;
+            std::vector<int> q;
+            pack_h2r(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, ph, c.w_plane, q);
+            void *dh = nullptr, *dsh = nullptr;
+            if ((rc = dev_upload(p, ph.data(), ph.size() * sizeof(uint16_t), &dh))) return rc;
+            std::vector<float> sh(rows);
+            for (int i = 0; i < rows; ++i) sh[i] = std::ldexp(scale[i], -q[i]);
+            if ((rc = dev_upload(p, sh.data(), rows * sizeof(float), &dsh))) return rc;
+            c.wh2r = dh;
+            c.scale_h2 = static_cast<const float*>(dsh);
+            c.xs_slot = p->range + 4 * (size_t)(&op - p->ops.data());
+            ++p->n_h2;
+        }
+    }
     if (op.c.set) {
         std::vector<float> s2(rows, 0.f), b2(rows, 0.f), s, b;
         if (kv_has(kv, "bias2")) {          // out2 = relu(v + bias2): the biased, activated copy beside a raw linear output
@@ -979,13 +1037,32 @@ static int launch_op(accel_plan* p, Op& op)
 }
 
 // Issues the plan: every op in list order on the context's compute stream (under stream capture this becomes a linear graph).
-static int run_eager(accel_plan* p)
+// probed: the range of the input of every fp16x2-form convolution is measured right before it runs and its pixel scale set from it
+// (device side, stream-ordered: no host round trip) -- the first run of a plan and its periodic re-calibrations.
+static int run_eager(accel_plan* p, bool probed = false)
 {
-    for (Op& op : p->ops) {
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        Op& op = p->ops[i];
+        if (probed && op.kind == OP_CONV && op.conv.xs_slot) {
+            const ConvParams& c = op.conv;
+            hipError_t e = launch_range_probe(c.x, (long)op.a.N * c.H * c.W, c.Cin, c.xCs, const_cast<float*>(c.xs_slot), p->range_flag_dev, (int)i, p->m->ctx->stream);
+            if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "range probe of conv %s failed: %s", op.name.c_str(), hipGetErrorString(e));
+        }
         int rc = launch_op(p, op);
         if (rc) return rc;
     }
     return 0;
+}
+
+// the sticky word a range probe raises (misc.hip range_set_kernel): a loud error instead of silently saturated frames
+static int range_check(accel_plan* p)
+{
+    if (!p->range_flag || !*p->range_flag) return 0;
+    const unsigned i = *p->range_flag - 1;
+    return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s is not finite or outgrew the half range at the scale it was calibrated to (fp16x2 form of the "
+                "fp32 layers: 32x of headroom over the calibrated maximum); frames since the last calibration are not trustworthy.  "
+                "ACCEL_RECAL_EVERY=<runs> (now %ld) re-calibrates more often, ACCEL_SPLIT=b3 selects the range-free bf16x3 form",
+                p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", p->recal_every);
 }
 
 // ---------------------------------------------------------------------------
@@ -1228,7 +1305,7 @@ static int autotune_plan(accel_plan* p)
         ConvParams& c = op.conv;
         TuneKey key; memset(&key, 0, sizeof key);
         int kk[16] = {c.H, c.W, c.Cin, c.xCs, c.Ho, c.Wo, c.kh * 16 + c.kw, c.sh * 16 + c.sw, c.dh * 16 + c.dw, c.K_pad,
-                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0) + 2048 * c.x_half + 4096 * c.y_half + 8192 * c.res_half + 16384 * (c.wstemb ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
+                      c.Cout_store, c.yCs, c.res ? c.resCs : 0, c.y2 ? c.y2Cs : 0, c.act + 8 * c.deconv2x + 16 * (c.f16 == 1) + 256 * (c.f16 == 2) + 32 * (c.wu ? 1 : 0) + 64 * (c.wstem ? 1 : 0) + 128 * (c.wws ? 1 : 0) + 512 * (c.wb3 ? 1 : 0) + 1024 * (c.wub ? 1 : 0) + 2048 * c.x_half + 4096 * c.y_half + 8192 * c.res_half + 16384 * (c.wstemb ? 1 : 0) + 32768 * (c.wh2r ? 1 : 0), c.ph * 16 + c.pw + 65536 * (c.M / (c.Ho * c.Wo))};
         memcpy(key.v, kk, sizeof kk);
         auto it = g_tune_cache.find(key);
         if (it != g_tune_cache.end()) {
@@ -1346,6 +1423,7 @@ static void plan_free(accel_plan* p)
     if (p->graph) hipGraphDestroy(p->graph);
     for (void* d : p->owned) hipFree(d);
     if (p->arena) hipFree(p->arena);
+    if (p->range_flag) hipHostFree(p->range_flag);
     delete p;
 }
 
@@ -1400,6 +1478,18 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         HIP_TRY(hipMalloc((void**)&p->arena, p->arena_bytes));
         poison(p->arena, p->arena_bytes);
         HIP_TRY(hipMemsetAsync(p->arena, 0, p->arena_bytes, p->m->ctx->stream));
+    }
+    {
+        std::vector<float> init(4 * p->ops.size() + 4, 0.f);
+        for (size_t i = 0; i < p->ops.size(); ++i) init[4 * i] = init[4 * i + 1] = 1.f;
+        HIP_TRY(hipMalloc((void**)&p->range, init.size() * sizeof(float)));
+        p->owned.push_back(p->range);
+        HIP_TRY(hipMemcpy(p->range, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipHostMalloc((void**)&p->range_flag, sizeof(unsigned), hipHostMallocMapped));
+        *p->range_flag = 0u;
+        HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
+        const char* re = getenv("ACCEL_RECAL_EVERY");
+        if (re) p->recal_every = atol(re);
     }
     for (Op& op : p->ops) {
         int rc = finalize_op(p, op);
@@ -1487,11 +1577,14 @@ extern "C" int accel_plan_run(accel_plan* p)
         int rc = accel_plan_run(ip->second);
         if (rc) return rc;
     }
-    int rc = 0;
-    if (p->gexec) {
+    int rc = range_check(p);
+    if (rc) return rc;
+    const bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
+    ++p->runs;
+    if (p->gexec && !probed) {
         if (hipGraphLaunch(p->gexec, m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipGraphLaunch failed");
     } else {
-        rc = run_eager(p);
+        rc = run_eager(p, probed);
     }
     for (const auto& w : p->pbuf_writes) m->source_written(w);
     for (const auto& w : p->pbuf_writes)
@@ -1527,7 +1620,32 @@ extern "C" int accel_plan_op_mode(accel_plan* p, int i, int* mode)
 {
     if (!p || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_mode: index out of range");
     const Op& op = p->ops[i];
-    if (mode) *mode = op.kind == OP_CONV ? op.conv.f16 : -1;
+    // 0: fp32 layer (bf16x3 form, six products on the bf16 pipe, where it runs on a matrix-core geometry), 1: f16-mode layer, 3: fp32 layer
+    // whose matrix-core geometries run the fp16x2 form (three products on the fp16 pipe)
+    if (mode) *mode = op.kind == OP_CONV ? (op.conv.f16 ? op.conv.f16 : (op.conv.wh2r ? 3 : 0)) : -1;
+    return 0;
+}
+
+extern "C" int accel_plan_op_range(accel_plan* p, int i, float* scale, int* calibrated)
+{
+    if (!p || !p->finalized || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_range: index out of range");
+    const Op& op = p->ops[i];
+    if (scale) *scale = 0.f;
+    if (calibrated) *calibrated = 0;
+    if (op.kind != OP_CONV || !op.conv.xs_slot) return 0;
+    float w[4];
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    HIP_TRY(hipMemcpy(w, op.conv.xs_slot, sizeof w, hipMemcpyDeviceToHost));
+    if (scale) *scale = w[0];
+    unsigned fl; memcpy(&fl, &w[3], 4);
+    if (calibrated) *calibrated = (int)(fl & 1u);
+    return 0;
+}
+
+extern "C" int accel_plan_recalibrate(accel_plan* p)
+{
+    if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_recalibrate: plan not finalized");
+    p->runs = 0;      // the next run probes
     return 0;
 }
 
@@ -1562,12 +1680,13 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
 extern "C" int accel_plan_run_serial(accel_plan* p)
 {
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run_serial: plan not finalized");
-    for (Op& op : p->ops) {
-        int rc = launch_op(p, op);
-        if (rc) return rc;
-    }
+    int rc = range_check(p);
+    if (rc) return rc;
+    const bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));      // as accel_plan_run
+    ++p->runs;
+    if ((rc = run_eager(p, probed))) return rc;
     HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
-    return 0;
+    return range_check(p);
 }
 
 extern "C" int accel_plan_arena_read(accel_plan* p, size_t offset, void* host_dst, size_t bytes, size_t* arena_bytes)

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     }
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const int HoWo = p.Ho * p.Wo;
+    const float xs = (NPL == 2 && p.xs) ? p.xs[0] : 1.f;      // power of two that centres the pixels in the half range (fp16x2 form)
 
     // ---- pixel-tile staging (same row order as conv_igemm_b3_kernel: rows of a group of 8 as 0,4,1,5,2,6,3,7) ------------
     const int t4 = tid / CPR;
@@ -138,6 +139,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { h[e] = (_Float16)ralo[set][i][e]; h[4 + e] = (_Float16)rahi[set][i][e]; }
                 *reinterpret_cast<i32x4*>(a + (srow + RP * i) * LDK + scol) = __builtin_bit_cast(i32x4, h);
+            } else if constexpr (NPL == 2) {
+                f16x8r h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? ralo[set][i][e] : rahi[set][i][e - 4];
+                    h[e] = (_Float16)(v * xs);
+                    l[e] = (_Float16)__builtin_fmaf(v, xs, -(float)h[e]);      // exact residual (one fma), then rounded to half
+                }
+                *reinterpret_cast<i32x4*>(a + (srow + RP * i) * LDK + scol) = __builtin_bit_cast(i32x4, h);
+                *reinterpret_cast<i32x4*>(a + (BM + srow + RP * i) * LDK + scol) = __builtin_bit_cast(i32x4, l);
             } else {
                 i32x4 q[3];
                 unsigned x0, x1, x2;
@@ -198,6 +209,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
                 if constexpr (NPL == 1) {
                     if constexpr ((ABL & 1) != 0) { asm volatile("" :: "v"(fa[set][i][0]), "v"(fbr[buf][j][0])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8r, fa[set][i][0]), __builtin_bit_cast(f16x8r, fbr[buf][j][0]), c, 0, 0, 0);
+                } else if constexpr (NPL == 2) {
+                    const f16x8r a0 = __builtin_bit_cast(f16x8r, fa[set][i][0]), a1 = __builtin_bit_cast(f16x8r, fa[set][i][1]);
+                    const f16x8r b0 = __builtin_bit_cast(f16x8r, fbr[buf][j][0]), b1 = __builtin_bit_cast(f16x8r, fbr[buf][j][1]);
+                    if constexpr ((ABL & 1) != 0) { asm volatile("" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1)); continue; }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);      // the two cross terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
                 } else {
                     const bf16x8r a0 = __builtin_bit_cast(bf16x8r, fa[set][i][0]), a1 = __builtin_bit_cast(bf16x8r, fa[set][i][1]),
                                   a2 = __builtin_bit_cast(bf16x8r, fa[set][i][2]);
@@ -288,6 +306,16 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
             case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 1>(p, st);
             case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 1>(p, st);
             case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 1>(p, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (p.f16 == 3) {
+        switch (tile) {
+            case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4, 0, 2>(p, st);
+            case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2, 0, 2>(p, st);
+            case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 2>(p, st);
+            case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 2>(p, st);
+            case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 2>(p, st);
             default: return hipErrorInvalidValue;
         }
     }

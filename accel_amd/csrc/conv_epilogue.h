@@ -56,6 +56,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // epilogue on 42 us residual layers.  So: every per-channel constant and EVERY residual value is fetched before the
     // first store is issued; after that the epilogue only computes and stores.
     float sc[NI], sf[NI], sc2[NI], sf2[NI];
+    const float xinv = p.xs ? p.xs[1] : 1.f;      // fp16x2 form: undo the pixel exponent (exact power of two)
     bool cok[NI];
     int co[NI];
 #pragma unroll
@@ -63,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         co[j] = n0 + (wn * NI + j) * 32 + (lane & 31);
         cok[j] = co[j] < p.Cout_store;
         const int cc = cok[j] ? co[j] : 0;
-        sc[j] = p.scale[cc]; sf[j] = p.shift[cc];
+        sc[j] = p.scale[cc] * xinv; sf[j] = p.shift[cc];
         sc2[j] = p.y2 ? p.scale2[cc] : 1.f; sf2[j] = p.y2 ? p.shift2[cc] : 0.f;
     }
     if (!RES_PER_J && p.res) {

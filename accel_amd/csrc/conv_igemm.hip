@@ -966,7 +966,7 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
         pix = ((size_t)n * p.yH + yy) * p.yW + xx;
     }
     const int co = c4 * 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co) * (p.xs ? p.xs[1] : 1.f);      // fp16x2 form: pixel exponent undone
     const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + co);
     f32x4 v = a * sc + sf;
     typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
@@ -1232,6 +1232,16 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         if (!p.wb3r) return hipErrorInvalidValue;
         ConvParams q = p;
         q.w = static_cast<const float*>(p.wb3r);
+        return launch_conv_b3r(q, p.force_tile, st);
+    }
+    if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && !p.f16 && p.wh2r) {
+        // the fp16x2 form of the same staging: two half planes per operand, three products
+        ConvParams q = p;
+        q.w = static_cast<const float*>(p.wh2r);
+        q.w_bytes = p.w_bytes / 2;
+        q.scale = p.scale_h2;
+        q.xs = p.xs_slot;
+        q.f16 = 3;
         return launch_conv_b3r(q, p.force_tile, st);
     }
     if (((p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6) || (p.force_tile >= 90 && p.force_tile <= 96)) && !p.f16) {

@@ -62,6 +62,15 @@ struct ConvParams {
     const void* wb3r;      // null where wb3 is null (or ACCEL_B3R=0)
     const void* wub;       // conv_wino_b3.hip: U = G g G^T as three bf16 planes [plane][C/16][16][wino_rows][16]; null: not offered
     unsigned wub_bytes;
+    // fp16x2 form of the bf16x3 kernels ("h2", ConvParams::f16 == 3 inside the launchers): every fp32 operand as hi + lo, two half
+    // terms (hi = RTNE(v), lo = RTNE(v - hi): 22-23 significant bits), THREE v_mfma_f32_32x32x16_f16 products per multiply-add
+    // (hi*hi + hi*lo + lo*hi), fp32 accumulate.  Operands are centred in the half range by exact powers of two: the weights per
+    // output channel on the host (folded into scale_h2), the pixels by *xs (device scalar pair {s, 1 / s}, set by the plan's range
+    // calibration), undone in the epilogue.
+    const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
+    const float* scale_h2; // scale[] with the weight exponents folded in
+    const float* xs;       // {s, 1 / s}; null = 1.  Set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
+    const float* xs_slot;  // the layer's slot in the plan's range table (accel_plan::range); null: no fp16x2 form
     // half activation storage (f16-mode plans; conv_b3d.hip NPL = 1 only): the view is stored as half (2 bytes per element, channel
     // strides in elements, x_bytes / y_bytes / res_bytes in bytes); values are rounded (RTNE) when stored, after the whole epilogue
     int x_half, y_half, res_half;
@@ -172,6 +181,8 @@ hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st);
 hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st);
 hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st);
+// range calibration of the fp16x2 form: max |x| of a convolution's input view -> the power-of-two pixel scale of its slot (misc.hip)
+hipError_t launch_range_probe(const float* x, long pixels, int C, int Cs, float* slot, unsigned* flag, int op_index, hipStream_t st);
 hipError_t launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st);      // flat device-to-device copy (one kernel, 16-byte accesses)
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st);   // Cout_store == 4, plain conv, no dual output
 hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,

@@ -3,6 +3,7 @@
 // channel axis (or along x for the NCHW boundary tensors), grid-stride free
 // (one element quad per thread, grids >> 256 CUs).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <math.h>
 #include "kernels.h"
@@ -816,5 +817,62 @@ __global__ void set_slot_kernel(const void** slot, const void* value) { *slot = 
 hipError_t launch_set_slot(const void** slot, const void* value, hipStream_t st)
 {
     hipLaunchKernelGGL(set_slot_kernel, dim3(1), dim3(1), 0, st, slot, value);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Range calibration of the fp16x2 form (kernels.h, ConvParams::xs).  A slot is four words per convolution:
+//   {s, 1 / s, bits of the largest |pixel| seen by the last probe, flags (bit 0: calibrated)}.
+// range_amax_kernel reduces max |x| over the view a convolution reads (pixels x C channels, channel stride Cs) into the slot
+// (non-negative floats order like their bit patterns, so one atomicMax on the bits; a NaN sorts above infinity and is caught
+// below); range_set_kernel turns it into the power of two that puts the largest pixel into [2^10, 2^11): 32x of headroom to
+// the largest half, full relative precision (two half terms, 22-23 bits) for every pixel down to 2^-13 of the largest and an
+// absolute error of 2^-36 of the largest below that.  The exponent only moves when the probed maximum has left [2^8, 2^12) at the
+// current scale (so that a re-calibration does not change results while the range is stable); a probe that finds the range past
+// the largest half at the scale the frames since the last probe were computed with -- or a non-finite input -- raises the
+// sticky flag the host checks (first offender's op index + 1).
+__global__ void range_amax_kernel(const float* __restrict__ x, long n4, int C4, int Cs, unsigned* __restrict__ slot)
+{
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * Cs + 4 * c4);
+        // max(|a|, |b|) on the bit patterns keeps a NaN visible (fmaxf would drop it)
+        const unsigned a = max(max(__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu),
+                               max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu));
+        m = __uint_as_float(max(__float_as_uint(m), a));
+    }
+    unsigned u = __float_as_uint(m);
+    for (int o = 32; o; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
+    if ((threadIdx.x & 63) == 0 && u) atomicMax(slot + 2, u);
+}
+
+__global__ void range_set_kernel(float* slot, unsigned* flag, int op_index)
+{
+    unsigned* us = reinterpret_cast<unsigned*>(slot);
+    const unsigned bits = us[2];
+    const bool calibrated = us[3] & 1u;
+    us[2] = 0u;
+    if (bits == 0u) return;                       // an all-zero input says nothing about the range: the scale stays
+    const float a = __uint_as_float(bits);
+    const float at_old = a * slot[0];
+    if (bits >= 0x7F800000u || (calibrated && at_old >= 61440.f)) { atomicCAS(flag, 0u, (unsigned)op_index + 1u); __threadfence_system(); }
+    if (bits >= 0x7F800000u) return;
+    if (calibrated && at_old >= 256.f && at_old < 4096.f) return;
+    int e = (int)((bits >> 23) & 0xFFu) - 126;    // a = m * 2^e, m in [0.5, 1)  (denormals: e = -126, scale clamped below)
+    e = 11 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    slot[0] = __uint_as_float((unsigned)(127 + e) << 23);
+    slot[1] = __uint_as_float((unsigned)(127 - e) << 23);
+    us[3] |= 1u;
+}
+
+hipError_t launch_range_probe(const float* x, long pixels, int C, int Cs, float* slot, unsigned* flag, int op_index, hipStream_t st)
+{
+    const long n4 = pixels * (C / 4);
+    const int blocks = (int)std::min<long>(2048, (n4 + 255) / 256);
+    if (blocks > 0) hipLaunchKernelGGL(range_amax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, C / 4, Cs, reinterpret_cast<unsigned*>(slot));
+    hipLaunchKernelGGL(range_set_kernel, dim3(1), dim3(1), 0, st, slot, flag, op_index);
     return hipGetLastError();
 }

@@ -53,6 +53,8 @@ def _declare(lib):
         "accel_model_add_plan": [vp, c.c_char_p, c.c_char_p, c.POINTER(vp)],
         "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_op_mode": [vp, c.c_int, c.POINTER(c.c_int)],
+        "accel_plan_op_range": [vp, c.c_int, c.POINTER(c.c_float), c.POINTER(c.c_int)],
+        "accel_plan_recalibrate": [vp],
         "accel_tune_stats": [c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],
@@ -348,6 +350,23 @@ class Plan(object):
             out.append({"kind": kind.value.decode(), "name": name.value.decode(), "flops": fl.value, "bytes": by.value,
                         "tile": t.value, "ksplit": k.value, "narrow": nw.value, "mode": md.value})
         return out
+
+    def ranges(self):
+        """fp16x2 form: {op name: (pixel scale, calibrated)} of the convolutions that have one (accel_plan_op_range)"""
+        out = {}
+        kind = ctypes.create_string_buffer(32)
+        name = ctypes.create_string_buffer(64)
+        for i in range(lib().accel_plan_num_ops(self.handle)):
+            s, cal = ctypes.c_float(), ctypes.c_int()
+            check(lib().accel_plan_op_range(self.handle, i, ctypes.byref(s), ctypes.byref(cal)))
+            if s.value:
+                check(lib().accel_plan_op_info(self.handle, i, kind, name, None, None))
+                out[name.value.decode()] = (s.value, bool(cal.value))
+        return out
+
+    def recalibrate(self):
+        """the next run measures the input ranges of the fp16x2-form convolutions again (accel_plan_recalibrate)"""
+        check(lib().accel_plan_recalibrate(self.handle))
 
     def run_serial(self):
         """diagnostics: every op in list order on the context stream (no graph replay), then a host wait"""

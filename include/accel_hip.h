@@ -43,6 +43,7 @@ typedef struct accel_plan accel_plan;     /* one bound graph (key or cur)       
 #define ACCEL_ERR_PLAN (-3)
 #define ACCEL_ERR_PARAM (-4)
 #define ACCEL_ERR_COMM (-5)
+#define ACCEL_ERR_RANGE (-6)   /* fp16x2 form: a convolution input outgrew the calibrated half range (accel_plan_run) */
 
 const char* accel_last_error(void);
 const char* accel_version(void);
@@ -86,8 +87,18 @@ int accel_plan_op_info(accel_plan* p, int i, char* kind32, char* name64, double*
 int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narrow);
 /* arithmetic mode of conv op i: 0 = fp32 layer (its launch geometry may still execute on the bf16 matrix cores as an exact
  * three-term split: tile 70-87), 1 = fp16-MFMA layer (plan option dtype=f16: ONE half product per multiply-add whatever the
- * geometry), 2 = bf16x3 layer (plan option dtype=bf16x3); -1 for non-conv ops.  Diagnostic only (bench.py prices families by it). */
+ * geometry), 2 = bf16x3 layer (plan option dtype=bf16x3), 3 = fp32 layer whose matrix-core geometries run the fp16x2 form (two half
+ * terms per operand, THREE half products per multiply-add; the default, plan option split=h2); -1 for non-conv ops.  Diagnostic only
+ * (bench.py prices families by it). */
 int accel_plan_op_mode(accel_plan* p, int i, int* mode);
+/* fp16x2 form: the power of two conv op i's pixels are multiplied by before the split (0 if the op has no such form) and whether a
+ * probed run has set it yet.  The first accel_plan_run of a plan, and every ACCEL_RECAL_EVERY-th after it (default 256, 0 = never
+ * again), measures max |x| of every such convolution's input right before it runs and sets the scale on the device so that the
+ * maximum lands in [2^10, 2^11); a probe that finds an input non-finite or past the half range at the scale in force makes the next
+ * accel_plan_run fail with ACCEL_ERR_RANGE.  accel_plan_recalibrate makes the next run a probed one.  (No reference counterpart:
+ * MXNet computes in fp32; this is the price of running fp32 layers as three half products.) */
+int accel_plan_op_range(accel_plan* p, int i, float* scale, int* calibrated);
+int accel_plan_recalibrate(accel_plan* p);
 /* Launch geometries are REPRODUCIBLE: decisions come from the table shipped beside the library (tune/gfx950.tune, covers
  * the BASELINE workloads) or from the user's table ($ACCEL_TUNE_CACHE, else ~/.cache/accel_amd/gfx950.tune); a shape in
  * neither is timed once and appended to the user's table.  Counters of this process: decisions replayed, decisions

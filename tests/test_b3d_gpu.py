@@ -14,6 +14,12 @@ pytestmark = pytest.mark.gpu
 B3D = [82, 83, 84, 85, 86, 87]
 
 
+@pytest.fixture(autouse=True)
+def bf16x3_split(monkeypatch):
+    """conv_b3d.hip has the bf16x3 form only (it is opt-in for fp32 layers): the comparisons with conv_b3r.hip are made in that form"""
+    monkeypatch.setenv("ACCEL_SPLIT", "b3")
+
+
 def rnd(seed, *shape, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
