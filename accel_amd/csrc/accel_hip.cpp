@@ -742,6 +742,17 @@ static int finalize_conv(accel_plan* p, Op& op)
                 if ((rc = dev_upload(p, ub.data(), ub.size() * sizeof(unsigned short), &db))) return rc;
                 c.wub = db;
                 c.wub_bytes = (unsigned)(ub.size() * sizeof(unsigned short));
+                if (c.xs_slot) {      // fp16x2 form of the layer: the same planes as two half terms
+                    std::vector<int> q;
+                    conv_wino_b3_pack_h2(w->data.data(), cout, cin, c.wino_rows, ub, q);
+                    void *dh = nullptr, *dsh = nullptr;
+                    if ((rc = dev_upload(p, ub.data(), ub.size() * sizeof(unsigned short), &dh))) return rc;
+                    std::vector<float> sh(rows, 0.f);
+                    for (int i = 0; i < rows && i < c.wino_rows; ++i) sh[i] = std::ldexp(scale[i], 2 - q[i]);      // x 4: V is split at a quarter of the pixel scale
+                    if ((rc = dev_upload(p, sh.data(), rows * sizeof(float), &dsh))) return rc;
+                    c.wubh = dh;
+                    c.scale_h2w = static_cast<const float*>(dsh);
+                }
             }
         } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
@@ -1059,6 +1070,7 @@ static int range_check(accel_plan* p)
 {
     if (!p->range_flag || !*p->range_flag) return 0;
     const unsigned i = *p->range_flag - 1;
+    *p->range_flag = 0u;      // reported once: the probe that raised it has already set the new scale
     return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s is not finite or outgrew the half range at the scale it was calibrated to (fp16x2 form of the "
                 "fp32 layers: 32x of headroom over the calibrated maximum); frames since the last calibration are not trustworthy.  "
                 "ACCEL_RECAL_EVERY=<runs> (now %ld) re-calibrates more often, ACCEL_SPLIT=b3 selects the range-free bf16x3 form",

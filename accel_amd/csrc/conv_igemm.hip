@@ -1211,9 +1211,18 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
-    if (p.force_tile == CONV_TILE_WINO_B3) return launch_conv_wino_b3(p, st);
-    if (p.force_tile == CONV_TILE_WINO_B3U) return launch_conv_wino_b3(p, st, true);
-    if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(p, st);
+    if (p.force_tile == CONV_TILE_WINO_B3 || p.force_tile == CONV_TILE_WINO_B3U || p.force_tile == CONV_TILE_WINO_B3S) {
+        ConvParams q = p;
+        if (p.wubh && !p.f16) {      // the fp16x2 form: two half planes of U, three products
+            q.wub = p.wubh;
+            q.wub_bytes = p.wub_bytes / 3 * 2;
+            q.scale = p.scale_h2w;
+            q.xs = p.xs_slot;
+            q.f16 = 3;
+        }
+        if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(q, st);
+        return launch_conv_wino_b3(q, st, p.force_tile == CONV_TILE_WINO_B3U);
+    }
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
     if (p.force_tile == CONV_TILE_STEM_B3) return launch_conv_stem_b3(p, st);
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
 // shapes the Winograd kernel takes: 3x3, stride 1, dilation 1, pad 1, even output size, channels in multiples of 8
 bool conv_wino_eligible(const ConvParams& p)
 {
-    return !p.deconv2x && !p.f16 && !p.narrow && p.kh == 3 && p.kw == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 &&
+    return !p.deconv2x && (!p.f16 || p.f16 == 3) && !p.narrow && p.kh == 3 && p.kw == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 &&
            p.ph == 1 && p.pw == 1 && p.Cin % (BKC * MS) == 0 && p.Ho == p.H && p.Wo == p.W && !(p.Ho & 1) && !(p.Wo & 1) && p.Cin >= 16;
 }
 

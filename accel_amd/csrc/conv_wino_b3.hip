@@ -25,6 +25,8 @@
 // (loader, as in conv_wino.hip: a thread owns one column of a 4x4 patch, B^T down the column, the row combination from
 // its quad neighbours by DPP), the split of the next position's fragments, the patch loads of the step after next.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -32,6 +34,7 @@
 #include "conv_common.h"
 
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
 // chunk swizzle of the raw patch copy: chunk c of pixel column x at slot c ^ bitrev2((x >> 2) & 3).  The patch-column reads of a
 // ds_read_b128 lane group (4 consecutive tiles, alternating channel quads: pixel columns x .. x+9) then hit 16 different slots.
 #define RAW_SWZ(x) (((((x) >> 2) & 1) << 1) | (((x) >> 3) & 1))
@@ -66,10 +69,14 @@ __device__ __forceinline__ void split3_pair_w(float v0, float v1, int& q0, int& 
 // UL (launch geometry 42): the block is a BH x BW rectangle of tiles (8x8, 4x16 or 2x32) and the UNION of its 64 patches --
 // (2 BH + 2) x (2 BW + 2) pixels, 20-25 KB per K step instead of 64 KB -- is loaded once, 64 contiguous bytes per 4 lanes, into
 // an LDS copy from which the threads take their patch columns (one more barrier per K step).
-template <int VAR, bool UL = false>
+// H2: the fp16x2 form (kernels.h): V and U as two half terms each, three v_mfma_f32_32x32x16_f16 products per multiply-add.  The
+// transformed patch B^T d B is up to 4x the largest pixel, so V is split at a quarter of the layer's calibrated pixel scale.
+template <int VAR, bool UL = false, bool H2 = false>
 __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NPW = H2 ? 2 : 3;      // planes per operand
+    const float xs = (H2 && p.xs) ? p.xs[0] * 0.25f : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;      // the factor 4 is in scale_h2w (host)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,15 +213,15 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     const unsigned u_step = 16u * u_pos;
     const unsigned u_plane = (unsigned)nk_all * u_step;
 
-    i32x4 fb[4][3];         // weight fragments of the four phases of a step, each requested a whole step ahead (right after the
+    i32x4 fb[4][NPW];       // weight fragments of the four phases of a step, each requested a whole step ahead (right after the
                             // MFMAs that used its registers): every wait on the in-order vector-memory counter is then for a load
                             // one step old, and the patch loads issued in between keep their lead
-    if constexpr ((VAR & 4) != 0) for (int b_ = 0; b_ < 4; ++b_) for (int pl = 0; pl < 3; ++pl) fb[b_][pl] = i32x4{lane, 1, 2, 3};
+    if constexpr ((VAR & 4) != 0) for (int b_ = 0; b_ < 4; ++b_) for (int pl = 0; pl < NPW; ++pl) fb[b_][pl] = i32x4{lane, 1, 2, 3};
     auto load_b = [&](int buf, int k, int pos, int jj) {
         if constexpr ((VAR & 4) != 0) return;
         const unsigned so = (unsigned)(kb + min(k, nk - 1)) * u_step + (unsigned)pos * u_pos + (unsigned)jj * 1024u;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, (VAR & 128) ? 2 : 0);
+        for (int pl = 0; pl < NPW; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, (VAR & 128) ? 2 : 0);
     };
     f32x4 raw[2][2];        // fp32 fragment of one position: [mi][channel half]
     auto read_raw = [&](int stage, int pos, int mi) {
@@ -222,9 +229,21 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         raw[mi][0] = *reinterpret_cast<const f32x4*>(v + a_rd0);
         raw[mi][1] = *reinterpret_cast<const f32x4*>(v + (a_rd0 ^ 4));      // channels 8h+4 .. 8h+7: slot ^ 1
     };
-    auto split_raw = [&](i32x4 (&a)[2][3], int mi) {
+    auto split_raw = [&](i32x4 (&a)[2][NPW], int mi) {
         if constexpr ((VAR & 16) != 0) {
-            a[mi][0] = __builtin_bit_cast(i32x4, raw[mi][0]); a[mi][1] = __builtin_bit_cast(i32x4, raw[mi][1]); a[mi][2] = a[mi][0] ^ a[mi][1];
+            a[mi][0] = __builtin_bit_cast(i32x4, raw[mi][0]); a[mi][1] = __builtin_bit_cast(i32x4, raw[mi][1]); a[mi][NPW - 1] = a[mi][0] ^ a[mi][1];
+            return;
+        }
+        if constexpr (H2) {
+            f16x8w h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = raw[mi][e >> 2][e & 3];
+                h[e] = (_Float16)(v * xs);
+                l[e] = (_Float16)__builtin_fmaf(v, xs, -(float)h[e]);      // exact residual, then rounded to half
+            }
+            a[mi][0] = __builtin_bit_cast(i32x4, h);
+            a[mi][NPW - 1] = __builtin_bit_cast(i32x4, l);
             return;
         }
         int q0[4], q1[4], q2[4];
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
         split3_pair_w(raw[mi][1][2], raw[mi][1][3], q0[3], q1[3], q2[3]);
         a[mi][0] = i32x4{q0[0], q0[1], q0[2], q0[3]};
         a[mi][1] = i32x4{q1[0], q1[1], q1[2], q1[3]};
-        a[mi][2] = i32x4{q2[0], q2[1], q2[2], q2[3]};
+        a[mi][NPW - 1] = i32x4{q2[0], q2[1], q2[2], q2[3]};
     };
 
     f32x16 acc[2][2][2];      // [own position][tile half mi][channel group jj]
@@ -249,19 +268,29 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 
     // 6 MFMAs on one accumulator tile: weight fragment = A operand (rows = channels), tile fragment = B operand (columns = tiles);
     // smallest terms first
-    auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[2][3], int mi) {
-        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+    auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[2][NPW], int mi) {
+        if constexpr (H2) {      // the two cross terms, then hi * hi
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            if constexpr ((VAR & 2) != 0) { asm volatile("" :: "v"(fb[buf][PB[t]]), "v"(a[mi][PA[t]])); continue; }
-            acc[pi][mi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, fb[buf][PB[t]]),
-                                                                      __builtin_bit_cast(bf16x8w, a[mi][PA[t]]), acc[pi][mi][jj], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) {
+                if constexpr ((VAR & 2) != 0) { asm volatile("" :: "v"(fb[buf][PB[t]]), "v"(a[mi][PA[t]])); continue; }
+                acc[pi][mi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, fb[buf][PB[t]]),
+                                                                         __builtin_bit_cast(f16x8w, a[mi][PA[t]]), acc[pi][mi][jj], 0, 0, 0);
+            }
+        } else {
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if constexpr ((VAR & 2) != 0) { asm volatile("" :: "v"(fb[buf][PB[t] % NPW]), "v"(a[mi][PA[t] % NPW])); continue; }
+                acc[pi][mi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, fb[buf][PB[t] % NPW]),
+                                                                          __builtin_bit_cast(bf16x8w, a[mi][PA[t] % NPW]), acc[pi][mi][jj], 0, 0, 0);
+            }
         }
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     const int P0 = 2 * wave, P1 = 2 * wave + 1;
-    i32x4 a0[2][3], a1[2][3];
+    i32x4 a0[2][NPW], a1[2][NPW];
 
     // ---- prologue: stage 0 = step 0 ----
     if constexpr (UL) {
@@ -297,9 +326,9 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 #define WB_FENCE() __builtin_amdgcn_sched_barrier(0)      /* the compiler keeps the order of what is on either side */
 #define WB_INTERLEAVE(nv)                                                                             \
     do {                                                                                              \
-        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                           \
+        _Pragma("unroll") for (int g_ = 0; g_ < (H2 ? 6 : 12); ++g_) {                                \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, (H2 ? 2 : 1) * (nv), 0);                      \
         }                                                                                             \
     } while (0)
     if constexpr (UL) {
@@ -466,7 +495,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
             for (int o = 0; o < 4; ++o) buf_store4(wr, ok ? (pix[o] * p.Cout_store + co) * 4u : OOB, v[o]);
         } else {
             const int cc = co < p.Cout_store ? co : 0;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc), sf = *reinterpret_cast<const f32x4*>(p.shift + cc);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc) * xinv, sf = *reinterpret_cast<const f32x4*>(p.shift + cc);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 v[o] = v[o] * sc + sf;
@@ -530,6 +559,43 @@ void conv_wino_b3_pack(const float* w, int Cout, int Cin, int rows, std::vector<
         }
 }
 
+// The fp16x2 form of the same planes (ConvParams::wubh): U * 2^q[k] as hi + lo, two half terms, q[k] putting the largest |U| of output
+// channel k into [2^14, 2^15) (see pack_h2r in accel_hip.cpp); qexp receives q per row.
+void conv_wino_b3_pack_h2(const float* w, int Cout, int Cin, int rows, std::vector<unsigned short>& out, std::vector<int>& qexp)
+{
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const size_t plane = (size_t)(Cin / BKC) * 16 * rows * BKC;
+    out.assign(2 * plane, 0);
+    qexp.assign(rows, 0);
+    std::vector<float> U((size_t)Cin * 16);
+    for (int k = 0; k < Cout; ++k) {
+        float amax = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+            const float* g = w + ((size_t)k * Cin + c) * 9;
+            double tmp[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int b = 0; b < 3; ++b) tmp[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
+            for (int i = 0; i < 4; ++i)
+                for (int jj = 0; jj < 4; ++jj) {
+                    double u = tmp[i][0] * G[jj][0] + tmp[i][1] * G[jj][1] + tmp[i][2] * G[jj][2];
+                    if (jj == 3) u = -u;
+                    const float f = (float)u;
+                    U[(size_t)c * 16 + i * 4 + jj] = f;
+                    amax = std::max(amax, std::fabs(f));
+                }
+        }
+        if (amax > 0.f && std::isfinite(amax)) { int e; std::frexp(amax, &e); qexp[k] = 15 - e; }
+        for (int c = 0; c < Cin; ++c)
+            for (int pos = 0; pos < 16; ++pos) {
+                const float v = std::ldexp(U[(size_t)c * 16 + pos], qexp[k]);
+                const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                const size_t at = (((size_t)(c / BKC) * 16 + pos) * rows + k) * BKC + (c % BKC);
+                memcpy(&out[at], &hi, 2);
+                memcpy(&out[plane + at], &lo, 2);
+            }
+    }
+}
+
 // geometry 42: tile-block shape for an output of TH x TW tiles, and the number of blocks
 long conv_wino_b3u_blocks(const ConvParams& p, int* bhs)
 {
@@ -569,7 +635,7 @@ hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_
             default: le = go(&conv_wino_b3_kernel<0, true>); break;
         }
 #else
-        le = go(&conv_wino_b3_kernel<0, true>);
+        le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, true, true>) : go(&conv_wino_b3_kernel<0, true>);
 #endif
     } else {
 #ifdef ACCEL_CONV_DIAG
@@ -592,7 +658,7 @@ hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_
         default: le = go(&conv_wino_b3_kernel<0>); break;
     }
 #else
-    le = go(&conv_wino_b3_kernel<0>);
+    le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, false, true>) : go(&conv_wino_b3_kernel<0>);
 #endif
     }
     if (le != hipSuccess) return le;

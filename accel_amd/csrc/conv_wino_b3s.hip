@@ -13,6 +13,7 @@
 #include "conv_common.h"
 
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 // chunk swizzle of the raw patch copy: chunk c of pixel column x at slot c ^ bitrev2((x >> 2) & 3).  The patch-column reads of a
 // ds_read_b128 lane group (4 consecutive tiles, alternating channel quads: pixel columns x .. x+9) then hit 16 different slots.
 #define RAW_SWZ(x) (((((x) >> 2) & 1) << 1) | (((x) >> 3) & 1))
@@ -42,9 +43,13 @@ __device__ __forceinline__ void split3_pair_s(float v0, float v1, int& q0, int& 
 }
 }  // namespace
 
+// H2: the fp16x2 form (see conv_wino_b3.hip): two half terms per operand, three v_mfma_f32_32x32x16_f16 products per multiply-add
+template <bool H2>
 __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NPW = H2 ? 2 : 3;
+    const float xs = (H2 && p.xs) ? p.xs[0] * 0.25f : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;      // the factor 4 is in scale_h2w (host)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,11 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
     const unsigned u_pos = (unsigned)p.wino_rows * 32u;
     const unsigned u_step = 16u * u_pos;
     const unsigned u_plane = (unsigned)nk_all * u_step;
-    i32x4 fb[4][3];         // weight fragments of four consecutive phases, each requested four phases (half a K step) ahead
+    i32x4 fb[4][NPW];       // weight fragments of four consecutive phases, each requested four phases (half a K step) ahead
     auto load_b = [&](int buf, int k, int pos, int jj) {
         const unsigned so = (unsigned)(kb + min(k, nk - 1)) * u_step + (unsigned)pos * u_pos + (unsigned)jj * 1024u;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, 0);
+        for (int pl = 0; pl < NPW; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, 0);
     };
     f32x4 raw[2];
     auto read_raw = [&](int stage, int pos) {
@@ -144,7 +149,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
         raw[0] = *reinterpret_cast<const f32x4*>(v + a_rd0);
         raw[1] = *reinterpret_cast<const f32x4*>(v + (a_rd0 ^ 4));
     };
-    auto split_raw = [&](i32x4 (&a)[3]) {
+    auto split_raw = [&](i32x4 (&a)[NPW]) {
+        if constexpr (H2) {
+            f16x8s h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = raw[e >> 2][e & 3];
+                h[e] = (_Float16)(v * xs);
+                l[e] = (_Float16)__builtin_fmaf(v, xs, -(float)h[e]);      // exact residual, then rounded to half
+            }
+            a[0] = __builtin_bit_cast(i32x4, h);
+            a[NPW - 1] = __builtin_bit_cast(i32x4, l);
+            return;
+        }
         int q0[4], q1[4], q2[4];
         split3_pair_s(raw[0][0], raw[0][1], q0[0], q1[0], q2[0]);
         split3_pair_s(raw[0][2], raw[0][3], q0[1], q1[1], q2[1]);
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
         split3_pair_s(raw[1][2], raw[1][3], q0[3], q1[3], q2[3]);
         a[0] = i32x4{q0[0], q0[1], q0[2], q0[3]};
         a[1] = i32x4{q1[0], q1[1], q1[2], q1[3]};
-        a[2] = i32x4{q2[0], q2[1], q2[2], q2[3]};
+        a[NPW - 1] = i32x4{q2[0], q2[1], q2[2], q2[3]};
     };
     f32x16 acc[4][2];      // [own position][channel group]
 #pragma unroll
@@ -161,17 +178,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][jj][e] = 0.f;
-    auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[3]) {
-        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+    auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[NPW]) {
+        if constexpr (H2) {      // the two cross terms, then hi * hi
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-            acc[pi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, fb[buf][PB[t]]),
-                                                                  __builtin_bit_cast(bf16x8s, a[PA[t]]), acc[pi][jj], 0, 0, 0);
+            for (int t = 0; t < 3; ++t)
+                acc[pi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fb[buf][PB[t]]),
+                                                                     __builtin_bit_cast(f16x8s, a[PA[t]]), acc[pi][jj], 0, 0, 0);
+        } else {
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[pi][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, fb[buf][PB[t] % NPW]),
+                                                                      __builtin_bit_cast(bf16x8s, a[PA[t] % NPW]), acc[pi][jj], 0, 0, 0);
+        }
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     const int P0 = 4 * wave;
-    i32x4 aA[3], aB[3];
+    i32x4 aA[NPW], aB[NPW];
 
     // ---- prologue ----
     load_g(0);
@@ -191,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 #define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define WS_INTERLEAVE(nv)                                                                             \
     do {                                                                                              \
-        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < (H2 ? 3 : 6); ++g_) {                                 \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, (H2 ? 2 : 1) * (nv), 0);                      \
         }                                                                                             \
     } while (0)
     // One K step = eight phases of 6 MFMAs (position x 32-channel group).  raw copy = patches of step k+1, g = patches of step k+2
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
             for (int o = 0; o < 4; ++o) buf_store4(wr, ok ? (pix[o] * p.Cout_store + co) * 4u : OOB, v[o]);
         } else {
             const int cc = co < p.Cout_store ? co : 0;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc), sf = *reinterpret_cast<const f32x4*>(p.shift + cc);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + cc) * xinv, sf = *reinterpret_cast<const f32x4*>(p.shift + cc);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 v[o] = v[o] * sc + sf;
@@ -364,8 +389,13 @@ hipError_t launch_conv_wino_b3s(const ConvParams& p0, hipStream_t st)
     p.wino_T = p.M / 4;
     p.MT = (int)conv_wino_b3s_blocks(p, &p.wino_bhs);
     p.NT = p.wino_rows / KKS;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_b3s_kernel), WBS_LDS); e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv_wino_b3s_kernel, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(256), WBS_LDS, st, p);
+    if (p.f16 == 3) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_b3s_kernel<true>), WBS_LDS); e != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_wino_b3s_kernel<true>, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(256), WBS_LDS, st, p);
+    } else {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_b3s_kernel<false>), WBS_LDS); e != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_wino_b3s_kernel<false>, dim3(p.MT * p.NT, p.ksplit > 1 ? p.ksplit : 1), dim3(256), WBS_LDS, st, p);
+    }
     if (p.ksplit > 1) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -69,6 +69,8 @@ struct ConvParams {
     // calibration), undone in the epilogue.
     const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
     const float* scale_h2; // scale[] with the weight exponents folded in
+    const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
+    const float* scale_h2w; // scale[] with U's exponents (and the factor 4 of the quarter-scale V split) folded in
     const float* xs;       // {s, 1 / s}; null = 1.  Set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
     const float* xs_slot;  // the layer's slot in the plan's range table (accel_plan::range); null: no fp16x2 form
     // half activation storage (f16-mode plans; conv_b3d.hip NPL = 1 only): the view is stored as half (2 bytes per element, channel
@@ -90,6 +92,7 @@ void conv_wino_pack(const float* w, int Cout, int Cin, int cin_pad, int rows, fl
 hipError_t launch_conv_wino(const ConvParams& p, hipStream_t st);
 bool conv_wino_b3_eligible(const ConvParams& p);
 void conv_wino_b3_pack(const float* w, int Cout, int Cin, int rows, std::vector<unsigned short>& out);
+void conv_wino_b3_pack_h2(const float* w, int Cout, int Cin, int rows, std::vector<unsigned short>& out, std::vector<int>& qexp);
 hipError_t launch_conv_wino_b3(const ConvParams& p, hipStream_t st, bool union_loader = false);
 long conv_wino_b3u_blocks(const ConvParams& p, int* bhs);
 long conv_wino_b3s_blocks(const ConvParams& p, int* bhs);

@@ -151,20 +151,25 @@ PIPES = {"conv_igemm_b3_kernel": (6.0, BF16_PEAK_TFLOPS, "bf16 MFMA, six product
          "conv_igemm_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"), "conv_stem_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"),
          "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (weight-stationary streaming 1x1)"),
          "conv_stem_b3_kernel": (6.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "bf16 MFMA, the 7x7/2 stems as six bf16 products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic)"),
+         "conv_h2_kernel": (3.0, BF16_PEAK_TFLOPS, "fp16 MFMA (same dense peak as bf16), THREE products per fp32 multiply-add (two half terms per operand, hi*hi + hi*lo + lo*hi): conv_b3r<NPL=2>"),
+         "conv_wino_h2_kernel": (3.0 / 2.25, BF16_PEAK_TFLOPS, "fp16 MFMA, Winograd F(2x2,3x3) position GEMMs as three half products each (conv_wino_b3 / conv_wino_b3s, H2)"),
          "conv_f16_kernel": (1.0, BF16_PEAK_TFLOPS, "fp16 MFMA, ONE half product per multiply-add (f16-mode layer on any geometry: conv_igemm_f16 / conv_b3r<NPL=1> / conv_b3d<NPL=1>)")}
 
 
 def conv_family(op, dtype="f32"):
     """Kernel family of one convolution launch.  `mode` (accel_plan_op_mode) is the arithmetic of the LAYER: an f16-mode layer
     executes one half product per multiply-add on whichever geometry it was given (70-87 included), an fp32 layer on geometries
-    70-87 executes the six products of the three-term bf16 split."""
+    70-87 executes the six products of the three-term bf16 split -- unless the layer is in its fp16x2 form (mode 3, the default), where
+    geometries 76-81 and 41-43 execute THREE half products (70-75, 82-87 and the stem keep the bf16x3 form)."""
     t, mode = op["tile"], op.get("mode", 1 if dtype == "f16" else 2 if dtype == "bf16x3" else 0)
     if op.get("narrow"):
         return "conv_narrow_kernel"
     if mode == 1:
         return "conv_f16_kernel"
     if t in (41, 42, 43):
-        return "conv_wino_b3_kernel"
+        return "conv_wino_h2_kernel" if mode == 3 else "conv_wino_b3_kernel"
+    if mode == 3 and 76 <= t <= 81:
+        return "conv_h2_kernel"
     if t == 40:
         return "conv_wino_f32_kernel"
     if t == 50:

@@ -42,6 +42,22 @@ def test_families_of_the_other_geometries():
     assert bench.conv_family(op(3, mode=2), "bf16x3") == "conv_igemm_b3_kernel"        # bf16x3 plan option on a classic geometry id
 
 
+def test_fp16x2_form_is_priced_at_three_products():
+    """mode 3 = an fp32 layer in its fp16x2 form: geometries 76-81 and the Winograd geometries 41-43 execute THREE half products per
+    multiply-add; the geometries that have no such form (70-75, 82-87, the stem) still execute the six of the bf16 split"""
+    fam = lambda t: bench.conv_family(op(t, mode=3), "f32")
+    for t in (76, 77, 79, 80, 81):
+        assert fam(t) == "conv_h2_kernel"
+    assert fam(41) == fam(42) == fam(43) == "conv_wino_h2_kernel"
+    assert fam(70) == fam(74) == fam(82) == fam(87) == "conv_igemm_b3_kernel" and fam(51) == "conv_stem_b3_kernel"
+    assert fam(40) == "conv_wino_f32_kernel" and fam(10) == "conv_igemm_f32_kernel"
+    assert bench.PIPES["conv_h2_kernel"][0] == 3.0 and bench.PIPES["conv_wino_h2_kernel"][0] == pytest.approx(3.0 / 2.25)
+    r = bench.roofline_from_launches([(op(76, mode=3), 1.0, 1)], "f32")       # 200 TF algorithmic -> 600 executed
+    assert r["kernel"] == "conv_h2_kernel" and r["frac"] == pytest.approx(3 * 200.0 / 2500.0)
+    rb = bench.roofline_from_launches([(op(76, mode=0), 1.0, 1)], "f32")      # the same launch of a bf16x3 layer: 1200 executed
+    assert rb["kernel"] == "conv_igemm_b3_kernel" and rb["frac"] == pytest.approx(6 * 200.0 / 2500.0)
+
+
 def test_roofline_is_split_by_regime():
     """a launch that moves its algorithmic bytes at >= 3 TB/s is priced against HBM, the others against the matrix pipe"""
     deep = (op(76, flops=2e11, nbytes=5e8), 1.0, 4)            # 0.5 TB/s: matrix regime, 200 TF algorithmic
