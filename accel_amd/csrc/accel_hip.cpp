@@ -780,6 +780,17 @@ static int finalize_conv(accel_plan* p, Op& op)
                 void* dsb = nullptr;
                 if ((rc = dev_upload(p, wb.data(), wb.size() * sizeof(unsigned short), &dsb))) return rc;
                 c.wstemb = dsb;
+                if (c.xs_slot) {      // fp16x2 form of the layer
+                    std::vector<int> q;
+                    conv_stem_b3_pack_h2(w->data.data(), cout, wb, q);
+                    void *dh = nullptr, *dsh = nullptr;
+                    if ((rc = dev_upload(p, wb.data(), wb.size() * sizeof(unsigned short), &dh))) return rc;
+                    std::vector<float> sh(rows, 0.f);
+                    for (int i = 0; i < rows && i < 64; ++i) sh[i] = std::ldexp(scale[i], -q[i]);
+                    if ((rc = dev_upload(p, sh.data(), rows * sizeof(float), &dsh))) return rc;
+                    c.wstemh = dh;
+                    c.scale_h2s = static_cast<const float*>(dsh);
+                }
             }
         } else if (c.force_tile == CONV_TILE_STEM || c.force_tile == CONV_TILE_STEM_B3) {
             return fail(ACCEL_ERR_ARG, "conv %s: the stem kernel takes 7x7 / stride 2 / pad 3 layers on 3-channel images with 64 "

@@ -1224,7 +1224,17 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         return launch_conv_wino_b3(q, st, p.force_tile == CONV_TILE_WINO_B3U);
     }
     if (p.force_tile == CONV_TILE_STEM) return launch_conv_stem(p, st);
-    if (p.force_tile == CONV_TILE_STEM_B3) return launch_conv_stem_b3(p, st);
+    if (p.force_tile == CONV_TILE_STEM_B3) {
+        if (p.wstemh && !p.f16) {      // the fp16x2 form
+            ConvParams q = p;
+            q.wstemb = p.wstemh;
+            q.scale = p.scale_h2s;
+            q.xs = p.xs_slot;
+            q.f16 = 3;
+            return launch_conv_stem_b3(q, st);
+        }
+        return launch_conv_stem_b3(p, st);
+    }
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
     const int b3d_tile = (p.force_tile < 0 && (p.x_half || p.y_half || p.res_half)) ? conv_pick_tile(p) : p.force_tile;
     if (b3d_tile >= CONV_TILE_B3D && b3d_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {

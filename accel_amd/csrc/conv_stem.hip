@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f32_kernel(ConvParams p, int
 // layers the stem kernel takes: 7x7 / stride 2 / pad 3 on a 3-channel NHWC4 image, 64 output channels, single output
 bool conv_stem_eligible(const ConvParams& p)
 {
-    return !p.deconv2x && !p.f16 && !p.narrow && p.kh == 7 && p.kw == 7 && p.sh == 2 && p.sw == 2 && p.dh == 1 && p.dw == 1 &&
+    return !p.deconv2x && (!p.f16 || p.f16 == 3) && !p.narrow && p.kh == 7 && p.kw == 7 && p.sh == 2 && p.sw == 2 && p.dh == 1 && p.dw == 1 &&
            p.ph == 3 && p.pw == 3 && p.Cin == 4 && p.Cout_store == 64 && !p.res && !p.y2;
 }
 

@@ -21,6 +21,8 @@
 //   * the MFMA takes the weights as the A operand: a lane ends up with 4 consecutive output channels of one pixel per accumulator
 //     quad -> 16-byte stores; scale / shift (BatchNorm) + ReLU fused.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <vector>
 #include <cstring>
 #include <cstdint>
@@ -34,8 +36,11 @@ constexpr int RWS = 408;                                 // floats per staged ro
 constexpr int WIN = IRH * RWS;                           // floats per window stage
 constexpr int NSTEP = 11;                                // K steps of 16 (22 chunks of 8; chunk 21 is all padding)
 constexpr int WBYTES = NSTEP * 2 * 3 * 64 * 16;          // weight fragments: [step][channel tile][plane][lane][8 bf16]
+constexpr int WBYTES_H2 = NSTEP * 2 * 2 * 64 * 16;       // the fp16x2 form: two half planes
 constexpr size_t STEMB_LDS = (size_t)WBYTES + 2 * WIN * sizeof(float) + 128 * sizeof(float);
+constexpr size_t STEMB_LDS_H2 = (size_t)WBYTES_H2 + 2 * WIN * sizeof(float) + 128 * sizeof(float);
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8sb __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3_pair_sb(float v0, float v1, unsigned& q0, unsigned& q1, unsigned& q2)
 {
@@ -49,10 +54,15 @@ __device__ __forceinline__ void split3_pair_sb(float v0, float v1, unsigned& q0,
 }
 }
 
+// H2: the fp16x2 form (kernels.h): two half terms per operand, three v_mfma_f32_32x32x16_f16 products per multiply-add
+template <bool H2>
 __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int tiles_x, int tiles_y, int ntiles)
 {
+    constexpr int NPS = H2 ? 2 : 3;
+    constexpr int WB = H2 ? WBYTES_H2 : WBYTES;
+    const float xs = (H2 && p.xs) ? p.xs[0] : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
-    float* win = reinterpret_cast<float*>(smem_sb + WBYTES);       // [2][WIN]
+    float* win = reinterpret_cast<float*>(smem_sb + WB);           // [2][WIN]
     float* ssc = win + 2 * WIN;                                    // [64 scale | 64 shift]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,8 +72,8 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
     {
         const i32x4* src = reinterpret_cast<const i32x4*>(p.w);
         i32x4* dst = reinterpret_cast<i32x4*>(smem_sb);
-        for (int i = tid; i < WBYTES / 16; i += 512) dst[i] = src[i];
-        if (tid < 64) { ssc[tid] = p.scale[tid]; ssc[64 + tid] = p.shift[tid]; }
+        for (int i = tid; i < WB / 16; i += 512) dst[i] = src[i];
+        if (tid < 64) { ssc[tid] = p.scale[tid] * xinv; ssc[64 + tid] = p.shift[tid]; }
     }
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
                 for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.f;
         // this lane's pixel of pixel tile a: output row `wave`, column 32 a + col; window row 2 wave + ky, float 6 (32 a + col) + 8 part
         const float* px0 = win + cur * WIN + (2 * wave) * RWS + 6 * col;
-        auto read_x = [&](int s, i32x4 (&xb)[2][3]) {
+        auto read_x = [&](int s, i32x4 (&xb)[2][NPS]) {
             int ch = 2 * s + kk;                      // chunk of 8 K values: kernel row ch / 3, part ch % 3
             if (ch > 20) ch = 20;                     // chunk 21 is all padding (zero weights): read chunk 20's floats again
             const int ky = ch / 3, part = ch - 3 * ky;
@@ -133,28 +143,45 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
             for (int a = 0; a < 2; ++a) {
                 const f32x2* q = reinterpret_cast<const f32x2*>(px0 + ky * RWS + 192 * a + 8 * part);
                 const f32x2 d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+                if constexpr (H2) {
+                    const float v8[8] = {d0[0], d0[1], d1[0], d1[1], d2[0], d2[1], d3[0], d3[1]};
+                    f16x8sb h, l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h[e] = (_Float16)(v8[e] * xs);
+                        l[e] = (_Float16)__builtin_fmaf(v8[e], xs, -(float)h[e]);      // exact residual, then rounded to half
+                    }
+                    xb[a][0] = __builtin_bit_cast(i32x4, h);
+                    xb[a][NPS - 1] = __builtin_bit_cast(i32x4, l);
+                    continue;
+                }
                 unsigned x0, x1, x2;
-                split3_pair_sb(d0[0], d0[1], x0, x1, x2); xb[a][0][0] = (int)x0; xb[a][1][0] = (int)x1; xb[a][2][0] = (int)x2;
-                split3_pair_sb(d1[0], d1[1], x0, x1, x2); xb[a][0][1] = (int)x0; xb[a][1][1] = (int)x1; xb[a][2][1] = (int)x2;
-                split3_pair_sb(d2[0], d2[1], x0, x1, x2); xb[a][0][2] = (int)x0; xb[a][1][2] = (int)x1; xb[a][2][2] = (int)x2;
-                split3_pair_sb(d3[0], d3[1], x0, x1, x2); xb[a][0][3] = (int)x0; xb[a][1][3] = (int)x1; xb[a][2][3] = (int)x2;
+                split3_pair_sb(d0[0], d0[1], x0, x1, x2); xb[a][0][0] = (int)x0; xb[a][1][0] = (int)x1; xb[a][NPS - 1][0] = (int)x2;
+                split3_pair_sb(d1[0], d1[1], x0, x1, x2); xb[a][0][1] = (int)x0; xb[a][1][1] = (int)x1; xb[a][NPS - 1][1] = (int)x2;
+                split3_pair_sb(d2[0], d2[1], x0, x1, x2); xb[a][0][2] = (int)x0; xb[a][1][2] = (int)x1; xb[a][NPS - 1][2] = (int)x2;
+                split3_pair_sb(d3[0], d3[1], x0, x1, x2); xb[a][0][3] = (int)x0; xb[a][1][3] = (int)x1; xb[a][NPS - 1][3] = (int)x2;
             }
         };
-        i32x4 xq[2][2][3];
+        i32x4 xq[2][2][NPS];
         read_x(0, xq[0]);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             if (s + 1 < NSTEP) read_x(s + 1, xq[(s + 1) & 1]);      // the next step's pixel operands are read and split beside this step's products
-            i32x4 wf[2][3];
+            i32x4 wf[2][NPS];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    wf[j][pl] = *reinterpret_cast<const i32x4*>(smem_sb + (((s * 2 + j) * 3 + pl) * 64 + lane) * 16);
+                for (int pl = 0; pl < NPS; ++pl)
+                    wf[j][pl] = *reinterpret_cast<const i32x4*>(smem_sb + (((s * 2 + j) * NPS + pl) * 64 + lane) * 16);
 #define SB_TERM(wp, xp)                                                                                                              \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
         acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, wf[j][wp]), __builtin_bit_cast(bf16x8s, xq[s & 1][a][xp]), acc[a][j], 0, 0, 0);
-            SB_TERM(1, 1) SB_TERM(0, 2) SB_TERM(2, 0) SB_TERM(0, 1) SB_TERM(1, 0) SB_TERM(0, 0)      // smallest terms first
+#define SH_TERM(wp, xp)                                                                                                              \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                      \
+        acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8sb, wf[j][wp]), __builtin_bit_cast(f16x8sb, xq[s & 1][a][xp]), acc[a][j], 0, 0, 0);
+            if constexpr (H2) { SH_TERM(1, 0) SH_TERM(0, 1) SH_TERM(0, 0) }                          // the two cross terms, then hi * hi
+            else { SB_TERM(1 % NPS, 1 % NPS) SB_TERM(0, 2 % NPS) SB_TERM(2 % NPS, 0) SB_TERM(0, 1 % NPS) SB_TERM(1 % NPS, 0) SB_TERM(0, 0) }      // smallest terms first
+#undef SH_TERM
 #undef SB_TERM
         }
         store_window(cur ^ 1);      // nobody reads that stage: its last readers passed the barrier that ended the previous tile
@@ -211,6 +238,29 @@ void conv_stem_b3_pack(const float* w, int Cout, std::vector<unsigned short>& ou
                 }
 }
 
+// The fp16x2 form of the same fragments (ConvParams::wstemh): w * 2^q[co] as hi + lo, two half terms; q[co] puts the channel's largest
+// weight into [2^14, 2^15) and is folded into the epilogue scale by the caller.
+void conv_stem_b3_pack_h2(const float* w, int Cout, std::vector<unsigned short>& out, std::vector<int>& qexp)
+{
+    out.assign((size_t)WBYTES_H2 / 2, 0);
+    qexp.assign(64, 0);
+    for (int co = 0; co < Cout && co < 64; ++co) {
+        float amax = 0.f;
+        for (int i = 0; i < 147; ++i) amax = std::max(amax, std::fabs(w[co * 147 + i]));
+        if (amax > 0.f && std::isfinite(amax)) { int e; std::frexp(amax, &e); qexp[co] = 15 - e; }
+    }
+    for (int s = 0; s < NSTEP; ++s)
+        for (int j = 0; j < 2; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = 2 * s + (lane >> 5), ky = ch / 3, e = 8 * (ch % 3) + i, kx = e / 3, c = e % 3, co = 32 * j + (lane & 31);
+                    const float r = (ch < 21 && e < 21 && co < Cout) ? std::ldexp(w[((co * 3 + c) * 7 + ky) * 7 + kx], qexp[co]) : 0.f;
+                    const _Float16 hi = (_Float16)r, lo = (_Float16)(r - (float)hi);
+                    memcpy(&out[((((size_t)s * 2 + j) * 2 + 0) * 64 + lane) * 8 + i], &hi, 2);
+                    memcpy(&out[((((size_t)s * 2 + j) * 2 + 1) * 64 + lane) * 8 + i], &lo, 2);
+                }
+}
+
 hipError_t launch_conv_stem_b3(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
@@ -227,7 +277,12 @@ hipError_t launch_conv_stem_b3(const ConvParams& p0, hipStream_t st)
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = ntiles < cus ? ntiles : cus;      // 135 KB of LDS: one persistent block per CU
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel), STEMB_LDS); e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv_stem_b3_kernel, dim3(grid), dim3(512), STEMB_LDS, st, p, tiles_x, tiles_y, ntiles);
+    if (p.f16 == 3) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<true>), STEMB_LDS_H2); e != hipSuccess) return e;
+        hipLaunchKernelGGL(conv_stem_b3_kernel<true>, dim3(grid), dim3(512), STEMB_LDS_H2, st, p, tiles_x, tiles_y, ntiles);
+        return hipGetLastError();
+    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<false>), STEMB_LDS); e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv_stem_b3_kernel<false>, dim3(grid), dim3(512), STEMB_LDS, st, p, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }

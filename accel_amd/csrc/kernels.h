@@ -69,6 +69,8 @@ struct ConvParams {
     // calibration), undone in the epilogue.
     const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
     const float* scale_h2; // scale[] with the weight exponents folded in
+    const void* wstemh;    // conv_stem_b3.hip: the stem's fragments as two half planes; null: not offered
+    const float* scale_h2s; // scale[] with the stem weights' exponents folded in
     const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
     const float* scale_h2w; // scale[] with U's exponents (and the factor 4 of the quarter-scale V split) folded in
     const float* xs;       // {s, 1 / s}; null = 1.  Set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
@@ -102,6 +104,7 @@ hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st
 #define CONV_TILE_STEM_B3 51      // the stem on the bf16 matrix cores, three exact bf16 terms per operand (conv_stem_b3.hip)
 bool conv_stem_b3_eligible(const ConvParams& p);
 void conv_stem_b3_pack(const float* w, int Cout, std::vector<unsigned short>& out);
+void conv_stem_b3_pack_h2(const float* w, int Cout, std::vector<unsigned short>& out, std::vector<int>& qexp);
 hipError_t launch_conv_stem_b3(const ConvParams& p, hipStream_t st);
 bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
