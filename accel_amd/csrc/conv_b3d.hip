@@ -50,7 +50,8 @@ __device__ __forceinline__ void split3_pair_d(float v0, float v1, unsigned& q0, 
 // fp16 form MI * NI: with one half step per barrier the fp16 form spent its time at barriers (0.13-0.18 of the fp16 peak on the
 // deep-K layers of config 5), so its stages hold 2 or 4 half steps; NS = ring depth (3: two stages in flight, 4: three)
 template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false, int KSUB = 1, int NS = 4>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
+__global__ __launch_bounds__(64 * WGM * WGN, (NS * KSUB * (BM * (XH ? 32 : 64) + NPL * BN * 32) <= 81920 ? 2 : 1))      // two blocks per CU where the LDS allows it
+void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!XH || NPL == 1, "half pixel storage belongs to the fp16 form");
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
     // the piece's kind do not depend on the half step): a wavefront issues KSUB * L1 or KSUB * (L1 - 1) pieces per stage
     constexpr int L1 = (NP1 + NW - 1) / NW, LMAX = KSUB * L1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+    const float xs = (NPL == 2 && p.xs) ? p.xs[0] : 1.f;      // power of two that centres the pixels in the half range (fp16x2 form)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,6 +211,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = (_Float16)lo[e]; h[4 + e] = (_Float16)hi[e]; }
                     fa[set][i][0] = __builtin_bit_cast(i32x4, h);
+                } else if constexpr (NPL == 2) {      // the split of conv_b3r<NPL = 2>: hi = RTNE(v s), lo = RTNE(v s - hi)
+                    f16x8d h, l;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = e < 4 ? lo[e & 3] : hi[e & 3];
+                        h[e] = (_Float16)(v * xs);
+                        l[e] = (_Float16)__builtin_fmaf(v, xs, -(float)h[e]);
+                    }
+                    fa[set][i][0] = __builtin_bit_cast(i32x4, h);
+                    fa[set][i][1] = __builtin_bit_cast(i32x4, l);
                 } else {
                     unsigned x0, x1, x2;
                     split3_pair_d(lo[0], lo[1], x0, x1, x2); fa[set][i][0][0] = (int)x0; fa[set][i][1][0] = (int)x1; fa[set][i][2][0] = (int)x2;
@@ -230,6 +242,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_b3d_kernel(ConvParams 
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, fa[set][i][0]), __builtin_bit_cast(f16x8d, fb[0]), acc[i][j], 0, 0, 0);
+            } else if constexpr (NPL == 2) {
+                const f16x8d b0 = __builtin_bit_cast(f16x8d, fb[0]), b1 = __builtin_bit_cast(f16x8d, fb[1]);
+                // the two cross terms, then hi * hi (the order of conv_b3r<NPL = 2>), the MI accumulators interleaved
+#define B3D_HTERM(ap, bp)                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, fa[set][i][ap]), bp, acc[i][j], 0, 0, 0);
+                B3D_HTERM(1, b0) B3D_HTERM(0, b1) B3D_HTERM(0, b0)
+#undef B3D_HTERM
             } else {
                 const bf16x8d b0 = __builtin_bit_cast(bf16x8d, fb[0]), b1 = __builtin_bit_cast(bf16x8d, fb[1]), b2 = __builtin_bit_cast(bf16x8d, fb[2]);
                 // the six terms, smallest first (the order of conv_b3r), the MI accumulators interleaved so that consecutive matrix
@@ -328,6 +348,21 @@ hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st)
         }
     }
     if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // half storage exists in the fp16 form only
+    if (p.f16 == 3) {
+        // the fp16x2 form (p.w = ConvParams::wh2r, two half planes; p.xs = the layer's range slot): three products per multiply-add,
+        // so a half step carries half the matrix work of the bf16x3 form
+        switch (tile) {
+            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 2>(p, st);                      // 128 KB of LDS, one block per CU
+            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 2>(p, st);                  // 96 KB
+            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 2>(p, st);                  // 64 KB: two blocks per CU
+            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 2>(p, st);
+            case CONV_TILE_B3D + 4: return launch_b3d<256, 256, 8, 1, 2>(p, st);                  // every pixel row split once
+            case CONV_TILE_B3D + 5: return launch_b3d<128, 256, 2, 4, 2>(p, st);
+            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 2>(p, st);                   // 48 KB: three blocks per CU
+            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 2>(p, st);                  // 96 KB
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (tile) {
         case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2>(p, st);          // 8 wavefronts, each 64 x 128: 160 KB of LDS, one block per CU
         case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2>(p, st);      // 8 wavefronts, each 32 x 128

@@ -1242,7 +1242,13 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         if (!p.wb3r || p.f16 == 2) return hipErrorInvalidValue;
         ConvParams q = p;
         q.w = static_cast<const float*>(p.wb3r);
-        if (!p.f16) { q.w_bytes = p.w_bytes / 2; q.f16 = 2; }
+        if (!p.f16 && p.wh2r) {      // the fp16x2 form of the layer: two half planes, three products, the pixel scale of its range slot
+            q.w = static_cast<const float*>(p.wh2r);
+            q.w_bytes = p.w_bytes / 2;
+            q.scale = p.scale_h2;
+            q.xs = p.xs_slot;
+            q.f16 = 3;
+        } else if (!p.f16) { q.w_bytes = p.w_bytes / 2; q.f16 = 2; }
         return launch_conv_b3d(q, b3d_tile, st);
     }
     if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // no other kernel reads or writes half views

@@ -151,6 +151,7 @@ PIPES = {"conv_igemm_b3_kernel": (6.0, BF16_PEAK_TFLOPS, "bf16 MFMA, six product
          "conv_igemm_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"), "conv_stem_f32_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA"),
          "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (weight-stationary streaming 1x1)"),
          "conv_stem_b3_kernel": (6.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "bf16 MFMA, the 7x7/2 stems as six bf16 products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic)"),
+         "conv_stem_h2_kernel": (3.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "fp16 MFMA, the 7x7/2 stems as three half products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic): conv_stem_b3<H2>"),
          "conv_h2_kernel": (3.0, BF16_PEAK_TFLOPS, "fp16 MFMA (same dense peak as bf16), THREE products per fp32 multiply-add (two half terms per operand, hi*hi + hi*lo + lo*hi): conv_b3r<NPL=2>"),
          "conv_wino_h2_kernel": (3.0 / 2.25, BF16_PEAK_TFLOPS, "fp16 MFMA, Winograd F(2x2,3x3) position GEMMs as three half products each (conv_wino_b3 / conv_wino_b3s, H2)"),
          "conv_f16_kernel": (1.0, BF16_PEAK_TFLOPS, "fp16 MFMA, ONE half product per multiply-add (f16-mode layer on any geometry: conv_igemm_f16 / conv_b3r<NPL=1> / conv_b3d<NPL=1>)")}
@@ -160,7 +161,7 @@ def conv_family(op, dtype="f32"):
     """Kernel family of one convolution launch.  `mode` (accel_plan_op_mode) is the arithmetic of the LAYER: an f16-mode layer
     executes one half product per multiply-add on whichever geometry it was given (70-87 included), an fp32 layer on geometries
     70-87 executes the six products of the three-term bf16 split -- unless the layer is in its fp16x2 form (mode 3, the default), where
-    geometries 76-81 and 41-43 execute THREE half products (70-75, 82-87 and the stem keep the bf16x3 form)."""
+    geometries 76-81, 41-43 and the stem (51) execute THREE half products (70-75 and 82-87 keep the bf16x3 form)."""
     t, mode = op["tile"], op.get("mode", 1 if dtype == "f16" else 2 if dtype == "bf16x3" else 0)
     if op.get("narrow"):
         return "conv_narrow_kernel"
@@ -175,7 +176,7 @@ def conv_family(op, dtype="f32"):
     if t == 50:
         return "conv_stem_f32_kernel"
     if t == 51:
-        return "conv_stem_b3_kernel"
+        return "conv_stem_h2_kernel" if mode == 3 else "conv_stem_b3_kernel"
     if t == 60:
         return "conv1x1_ws_kernel"
     if mode == 2 or 70 <= t <= 87:
@@ -555,10 +556,17 @@ def _run(a):
                "baseline_note": "BASELINE.md 1: reference README 0.44 s/frame Accel-18 on 1x Tesla K80, batch 1, including H2D of the "
                                 "frame and D2H of the label map; vs_baseline = secondary.accel18_batch1_pcie_inclusive / that number "
                                 "(same timing definition, other hardware), null when that secondary was not measured",
-               "dtype": ("f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
-                         "and, for most implicit-GEMM layers, 'bf16x3': each fp32 operand split EXACTLY into three bf16 terms, six bf16 "
-                         "MFMA products accumulated in fp32 -- error against float64 equal to the fp32-MFMA kernel's, "
-                         "tests/test_bf16x3_gpu.py; secondary.*_fp32_mfma_only = without them)"
+               "dtype": (("f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
+                          "and, for most layers, 'fp16x2': each fp32 operand as TWO half terms hi + lo (22-23 significant bits, operands "
+                          "centred in the half range by exact powers of two: weights per channel, pixels by a probed per-layer scale), "
+                          "three fp16 MFMA products hi*hi + hi*lo + lo*hi accumulated in fp32 -- error against float64 equal to the "
+                          "bf16x3 form's and below an fp32 accumulation's, tests/test_h2_gpu.py; secondary.*_bf16x3_split = the range-free "
+                          "three-term bf16 form (six products), secondary.*_fp32_mfma_only = neither)"
+                          if os.environ.get("ACCEL_SPLIT", "h2") == "h2" else
+                          "f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
+                          "and, for most implicit-GEMM layers, 'bf16x3': each fp32 operand split EXACTLY into three bf16 terms, six bf16 "
+                          "MFMA products accumulated in fp32 -- error against float64 equal to the fp32-MFMA kernel's, "
+                          "tests/test_bf16x3_gpu.py; secondary.*_fp32_mfma_only = without them)")
                          if os.environ.get("ACCEL_BF16X3", "1") != "0" else "f32 (fp32 MFMA only: ACCEL_BF16X3=0)") if a.dtype == "f32" else
                         "f32 as 3 x bf16 (each fp32 operand split exactly into three bf16 terms, six products per multiply-add on the bf16 "
                         "matrix cores, f32 storage + accumulate; error vs float64 equal to the fp32-MFMA kernel's, tests/test_bf16x3_gpu.py)"
@@ -651,6 +659,23 @@ def _run(a):
                 sec["accel18_batch%d_fp32_mfma_only" % B] = {"error": repr(e)}
             finally:
                 os.environ.pop("ACCEL_BF16X3", None)
+        if a.dtype == "f32" and os.environ.get("ACCEL_BF16X3", "1") != "0" and os.environ.get("ACCEL_SPLIT", "h2") == "h2":
+            # the headline again with the range-free three-term bf16 split (six products) instead of fp16x2 (three): the A/B of the form
+            try:
+                os.environ["ACCEL_SPLIT"] = "b3"
+                w4 = Workload(a.version, B, H, W, a.interval, local_rank, rank, config)
+                el = w4.timed(steps2, warm2)
+                rf = w4.conv_roofline(a.dtype)
+                sec["accel18_batch%d_bf16x3_split" % B] = {
+                    "value": rate(w4, el, steps2), "unit": "frames/s", "clips_per_call": B,
+                    "what": "the headline workload with ACCEL_SPLIT=b3: every matrix-core geometry in its bf16x3 form (three exact bf16 "
+                            "terms per operand, six products, no range calibration) instead of fp16x2",
+                    "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_peak": rf["all_conv"]["frac"]}
+                w4.close()
+            except Exception as e:
+                sec["accel18_batch%d_bf16x3_split" % B] = {"error": repr(e)}
+            finally:
+                os.environ.pop("ACCEL_SPLIT", None)
         # BASELINE config 5 (reduced precision, never the headline): Accel-50, fp16-MFMA convolutions (operands rounded to half
         # by the loader, fp32 storage + accumulate), 2048x4096, key-frame interval 10, one clip
         try:

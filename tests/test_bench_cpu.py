@@ -44,12 +44,13 @@ def test_families_of_the_other_geometries():
 
 def test_fp16x2_form_is_priced_at_three_products():
     """mode 3 = an fp32 layer in its fp16x2 form: geometries 76-81 and the Winograd geometries 41-43 execute THREE half products per
-    multiply-add; the geometries that have no such form (70-75, 82-87, the stem) still execute the six of the bf16 split"""
+    multiply-add (the stem, 51, over its padded K); the geometries that have no such form (70-75, 82-87) still execute the six of the bf16 split"""
     fam = lambda t: bench.conv_family(op(t, mode=3), "f32")
     for t in (76, 77, 79, 80, 81):
         assert fam(t) == "conv_h2_kernel"
     assert fam(41) == fam(42) == fam(43) == "conv_wino_h2_kernel"
-    assert fam(70) == fam(74) == fam(82) == fam(87) == "conv_igemm_b3_kernel" and fam(51) == "conv_stem_b3_kernel"
+    assert fam(70) == fam(74) == fam(82) == fam(87) == "conv_igemm_b3_kernel"
+    assert fam(51) == "conv_stem_h2_kernel" and bench.PIPES["conv_stem_h2_kernel"][0] == pytest.approx(3 * 176 / 147)
     assert fam(40) == "conv_wino_f32_kernel" and fam(10) == "conv_igemm_f32_kernel"
     assert bench.PIPES["conv_h2_kernel"][0] == 3.0 and bench.PIPES["conv_wino_h2_kernel"][0] == pytest.approx(3.0 / 2.25)
     r = bench.roofline_from_launches([(op(76, mode=3), 1.0, 1)], "f32")       # 200 TF algorithmic -> 600 executed

@@ -176,3 +176,20 @@ def test_split_b3_plan_option_and_env(ctx, monkeypatch):
         assert c.plan.ranges() == {} and [o["mode"] for o in c.plan.ops() if o["kind"] == "conv"] == [0]
     finally:
         c.close()
+
+
+def test_stem_fp16x2_is_as_accurate_as_bf16x3(ctx, monkeypatch):
+    """the 7x7/2 stem (geometry 51, conv_stem_b3.hip) in both forms against a float64 convolution: images of the scale the
+    reference feeds (mean-subtracted 8-bit pixels), tiny ones and large ones; ragged tiles"""
+    import torch
+    import torch.nn.functional as F
+    for xscale, wscale in ((50.0, 0.002), (1e-3, 1.0), (2e3, 1e-4)):
+        x, w = rnd(90, 2, 3, 120, 200, scale=xscale), rnd(91, 64, 3, 7, 7, scale=wscale)
+        truth = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=2, padding=3).numpy()
+        sc = float(np.abs(truth).max())
+        err = {}
+        for form in ("b3", "h2"):
+            monkeypatch.setenv("ACCEL_SPLIT", form)
+            err[form] = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=51) - truth).max()) / sc
+        print("stem vs float64 at pixel scale %g: bf16x3 %.2e, fp16x2 %.2e" % (xscale, err["b3"], err["h2"]))
+        assert err["h2"] <= 3e-6 and err["h2"] <= 1.5 * err["b3"] + 1e-7, (xscale, err)
