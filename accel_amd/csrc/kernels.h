@@ -69,6 +69,11 @@ struct ConvParams {
     // calibration), undone in the epilogue.
     const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
     const float* scale_h2; // scale[] with the weight exponents folded in
+    // conv_stem_b3.hip, pooled form: the 3x3 / stride-2 max pooling behind the stem computed by the stem kernel itself; y / yCs are then
+    // the POOLED image (pool_Ho x pool_Wo), Ho / Wo stay the conv image's.  pool_pad: conv rows / columns in front of the first window (0: pad 0,
+    // 'full' convention; 1: pad 1); pool_scale / pool_shift / pool_relu: the pooling op's own BatchNorm + ReLU epilogue (null: none)
+    int pool, pool_pad, pool_Ho, pool_Wo, pool_relu;
+    const float* pool_scale; const float* pool_shift;
     const void* wstemh;    // conv_stem_b3.hip: the stem's fragments as two half planes; null: not offered
     const float* scale_h2s; // scale[] with the stem weights' exponents folded in
     const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
