@@ -32,7 +32,7 @@ def _bind_and_run(version, cfg, arg, aux, data, nframes=3):
     return r, outs
 
 
-@pytest.mark.parametrize("version,binds", [("18", 8), ("34", 4), ("50", 4), ("101", 4), ("dff", 3)])
+@pytest.mark.parametrize("version,binds", [("18", 4), ("34", 2), ("50", 2), ("101", 2), ("dff", 2)])
 def test_every_binding_computes_the_same_frames(demo_cfg, version, binds):
     from accel_amd import demo
     demo_cfg.SCALES[0] = (H, W)
@@ -60,7 +60,7 @@ def test_graph_replay_equals_the_serial_run_of_the_same_binding(demo_cfg, monkey
     demo_cfg.SCALES[0] = (H, W)
     arg, aux = synth.model_params("18", H, W, demo_cfg)
     data = demo.build_batches(synth.make_clip(H, W, 2), demo_cfg)
-    for it in range(4):
+    for it in range(2):
         r, outs = _bind_and_run("18", demo_cfg, arg, aux, data, nframes=2)
         try:
             plan, lw = r.cur_predictor.plan_for(H, W, 1)
