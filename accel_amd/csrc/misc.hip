@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <math.h>
 #include "kernels.h"
 
@@ -122,9 +123,54 @@ __global__ void pool_kernel(PoolParams p)
     *reinterpret_cast<float4*>(p.y + blockIdx.z * p.y_img + (size_t)pix * p.yCs + c4 * 4) = acc;
 }
 
+// max 3x3 / stride 2 (both conventions: the windows are clipped to the image): the nine taps as nine independent 16-byte loads in
+// flight (the general kernel's loops have run-time bounds: one load, one wait, one maximum at a time).  Same values: a maximum is exact.
+__global__ void pool_max3x3s2_kernel(PoolParams p)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.Ho * p.Wo * p.C4;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % p.C4);
+    const int pix = (int)(idx / p.C4);
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    const int hs = oy * 2 - p.ph, ws = ox * 2 - p.pw;
+    const float* x = p.x + blockIdx.z * p.x_img + c4 * 4;
+    float4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = hs + t / 3, ix = ws + t % 3;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int cy = ok ? iy : 0, cx = ok ? ix : 0;
+        v[t] = *reinterpret_cast<const float4*>(x + ((size_t)cy * p.W + cx) * p.xCs);
+        if (!ok) v[t] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float4 acc = v[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) {
+        acc.x = v[t].x > acc.x ? v[t].x : acc.x; acc.y = v[t].y > acc.y ? v[t].y : acc.y;
+        acc.z = v[t].z > acc.z ? v[t].z : acc.z; acc.w = v[t].w > acc.w ? v[t].w : acc.w;
+    }
+    if (p.scale) {
+        const float4 s = *reinterpret_cast<const float4*>(p.scale + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.shift + c4 * 4);
+        acc.x = acc.x * s.x + b.x; acc.y = acc.y * s.y + b.y;
+        acc.z = acc.z * s.z + b.z; acc.w = acc.w * s.w + b.w;
+    }
+    if (p.relu) {
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+        acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(p.y + blockIdx.z * p.y_img + (size_t)pix * p.yCs + c4 * 4) = acc;
+}
+
 hipError_t launch_pool(const PoolParams& p, hipStream_t st)
 {
     const long total = (long)p.Ho * p.Wo * p.C4;
+    static const char* pe = getenv("ACCEL_POOL_GENERIC");
+    if (p.is_max && p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2 && !(pe && pe[0] == '1')) {
+        hipLaunchKernelGGL(pool_max3x3s2_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pool_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
     return hipGetLastError();
 }
