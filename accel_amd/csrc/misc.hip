@@ -208,18 +208,12 @@ __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
     const bool x0 = tx >= 0 && tx <= W - 1, x1 = tx + 1 >= 0 && tx + 1 <= W - 1;
     const bool y0 = ty >= 0 && ty <= H - 1, y1 = ty + 1 >= 0 && ty + 1 <= H - 1;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tl = z, tr = z, bl = z, br = z;
     const float* base = feat + c4 * 4;
-    // the four taps as four unconditional loads (clamped addresses, the out-of-range ones replaced by zero afterwards): all in flight
-    // together instead of one guarded load after the other
-    const int cy0 = y0 ? ty : 0, cy1 = y1 ? ty + 1 : 0, cx0 = x0 ? tx : 0, cx1 = x1 ? tx + 1 : 0;
-    float4 tl = *reinterpret_cast<const float4*>(base + ((size_t)cy0 * W + cx0) * fCs);
-    float4 tr = *reinterpret_cast<const float4*>(base + ((size_t)cy0 * W + cx1) * fCs);
-    float4 bl = *reinterpret_cast<const float4*>(base + ((size_t)cy1 * W + cx0) * fCs);
-    float4 br = *reinterpret_cast<const float4*>(base + ((size_t)cy1 * W + cx1) * fCs);
-    if (!(x0 && y0)) tl = z;
-    if (!(x1 && y0)) tr = z;
-    if (!(x0 && y1)) bl = z;
-    if (!(x1 && y1)) br = z;
+    if (x0 && y0) tl = *reinterpret_cast<const float4*>(base + ((size_t)ty * W + tx) * fCs);
+    if (x1 && y0) tr = *reinterpret_cast<const float4*>(base + ((size_t)ty * W + tx + 1) * fCs);
+    if (x0 && y1) bl = *reinterpret_cast<const float4*>(base + ((size_t)(ty + 1) * W + tx) * fCs);
+    if (x1 && y1) br = *reinterpret_cast<const float4*>(base + ((size_t)(ty + 1) * W + tx + 1) * fCs);
     const float w00 = wy * wx, w01 = wy * (1.0f - wx), w10 = (1.0f - wy) * wx, w11 = (1.0f - wy) * (1.0f - wx);
     float4 o;
     // tl*wy*wx evaluates as (tl*wy)*wx in the reference expression; keep that association
