@@ -169,6 +169,17 @@ def test_flow_warp(ctx, mag):
         close(O.flow_warp(feat, flow), feat, 1e-5)
 
 
+def test_flow_warp_reproduces_the_mxnet_docstring_example(ctx):
+    """the worked example of MXNet's BilinearSampler documentation for the `warp` grid (tests/test_pins_cpu.py holds the same vector for the
+    oracle): flow (1, 0) shifts the image one pixel to the left, zeros come in from outside -- exact on the device too"""
+    data = np.array([[[[1, 4, 3, 6], [1, 8, 8, 9], [0, 4, 1, 5], [1, 0, 1, 3]]]], np.float32)
+    want = np.array([[[[4, 3, 6, 0], [8, 8, 9, 0], [4, 1, 5, 0], [0, 1, 3, 0]]]], np.float32)
+    flow = np.zeros((1, 2, 4, 4), np.float32)
+    flow[:, 0] = 1.0
+    got = ctx.flow_warp(np.repeat(data, 4, axis=1), flow)      # the kernel moves channel quads
+    assert np.array_equal(got, np.repeat(want, 4, axis=1))
+
+
 def test_flow_input(ctx):
     cur, prev = rnd(24, 1, 3, 32, 64, scale=60), rnd(25, 1, 3, 32, 64, scale=60)
     data = np.concatenate([cur / np.float32(255.0), prev / np.float32(255.0)], axis=1)

@@ -258,3 +258,47 @@ def test_resize_inter_linear_hand_computed_cases():
     # stride padding: zeros to the next multiple (image.py:213-220)
     pad, _ = resize(np.ones((5, 7, 3)), 5, 7, stride=4)
     assert pad.shape == (8, 8, 3) and pad[:5, :7].min() == 1 and pad[5:].max() == 0 and pad[:, 7:].max() == 0
+
+
+# ---- the published examples of the dependency itself ---------------------------------------------------------------------------
+# MXNet is un-vendored (the path's arithmetic lives in mxnet @ 62ecb60), but its operator documentation carries worked
+# examples; the two below are the docstring of `BilinearSampler` (src/operator/bilinear_sampler.cc, "Example 1" zoom out by an affine
+# grid, "Example 2" the `warp` grid this path uses: accel_18.py:174-175, resnet_v1_101_flownet_deeplab.py get_*_test_symbol).
+DOC_DATA = np.array([[[[1, 4, 3, 6], [1, 8, 8, 9], [0, 4, 1, 5], [1, 0, 1, 3]]]], np.float32)
+
+
+def test_mxnet_docstring_example_warp_grid_and_bilinear_sampler():
+    """flow = (1, 0) everywhere: GridGenerator(transform_type='warp') + BilinearSampler shift the image one pixel to the left,
+    the column that would come from outside is zero"""
+    flow = np.zeros((1, 2, 4, 4), np.float32)
+    flow[:, 0] = 1.0                                       # channel 0 = horizontal displacement
+    want = np.array([[[[4, 3, 6, 0], [8, 8, 9, 0], [4, 1, 5, 0], [0, 1, 3, 0]]]], np.float32)
+    got = O.bilinear_sampler(DOC_DATA, O.grid_generator_warp(flow))
+    assert np.array_equal(got, want)
+    assert np.array_equal(O.flow_warp(DOC_DATA, flow), want)
+    # the grid itself, from the operator's definition: x_src = (x + flow_x) / ((W - 1) / 2) - 1
+    grid = O.grid_generator_warp(flow)
+    xs = (np.arange(4, dtype=np.float32) + 1) / np.float32(1.5) - 1
+    assert np.allclose(grid[0, 0], np.tile(xs, (4, 1)), atol=1e-6)
+    assert np.allclose(grid[0, 1], np.tile(((np.arange(4, dtype=np.float32)) / np.float32(1.5) - 1)[:, None], (1, 4)), atol=1e-6)
+
+
+def test_mxnet_docstring_example_affine_zoom_out_through_bilinear_sampler():
+    """affine_matrix = [[2, 0, 0], [0, 2, 0]], target 4x4: the sampler sees the grid 2 * (x_t, y_t) with x_t, y_t in {-1, -1/3, 1/3, 1};
+    the documentation's output has the four interior means and zeros where the grid leaves [-1, 1]"""
+    t = np.linspace(-1, 1, 4, dtype=np.float32)
+    grid = np.stack([np.tile(2 * t, (4, 1)), np.tile((2 * t)[:, None], (1, 4))])[None].astype(np.float32)
+    want = np.array([[[[0, 0, 0, 0], [0, 3.5, 6.5, 0], [0, 1.25, 2.5, 0], [0, 0, 0, 0]]]], np.float32)
+    assert np.allclose(O.bilinear_sampler(DOC_DATA, grid), want, atol=1e-6)
+
+
+def test_mxnet_documented_output_size_rules():
+    """Pooling: 'valid' floor((x + 2p - k) / s) + 1, 'full' ceil((x + 2p - k) / s) + 1 (operator docs); Deconvolution:
+    (x - 1) s - 2p + k.  The sizes the path depends on: pool1 of the ResNet-101 stem ('full': 512 -> 256, 514 -> 257 where 'valid'
+    gives 256), pooling0 of the ResNet-18 branch (pad 1: 512 -> 256), FlowNet's 4x4/2 deconvolutions (pad 1: x -> 2x; pad 0 then Crop:
+    x -> 2x + 2), the 32x32/16 score upsampler (x -> 16 x + 16, cropped by 8)"""
+    size = lambda n, k, s, p, conv: O.pool2d(np.zeros((1, 1, n, n), np.float32), "max", k, s, p, conv).shape[-1]
+    assert size(512, 3, 2, 0, "full") == 256 and size(514, 3, 2, 0, "full") == 257 and size(514, 3, 2, 0, "valid") == 256
+    assert size(512, 3, 2, 1, "valid") == 256 and size(7, 3, 2, 0, "full") == 3 and size(8, 3, 2, 0, "full") == 4 and size(8, 3, 2, 0, "valid") == 3
+    dec = lambda n, k, s, p: O.deconv2d(np.zeros((1, 1, n, n), np.float32), np.zeros((1, 1, k, k), np.float32), None, s, p).shape[-1]
+    assert dec(16, 4, 2, 1) == 32 and dec(16, 4, 2, 0) == 34 and dec(64, 32, 16, 0) == 16 * 64 + 16
