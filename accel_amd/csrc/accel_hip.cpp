@@ -734,7 +734,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                     a0_ = e_ + 1;
                 }
             }
-            const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S || c.force_tile == CONV_TILE_WINO_H2W;
+            const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S;
             if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0') && wb3_ok) || wb3_forced) && !c.f16 && conv_wino_b3_eligible(c)) {
                 // the same transformed weights as three exact bf16 planes in MFMA fragment order: launch geometry 41
                 std::vector<unsigned short> ub;
@@ -755,7 +755,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                     c.scale_h2w = static_cast<const float*>(dsh);
                 }
             }
-        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S || c.force_tile == CONV_TILE_WINO_H2W) {
+        } else if (c.force_tile == CONV_TILE_WINO || c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S) {
             return fail(ACCEL_ERR_ARG, "conv %s: the Winograd kernel takes 3x3 / stride 1 / dilation 1 / pad 1 layers with even output "
                                        "size and channels in multiples of 8 only", op.name.c_str());
         }
@@ -1255,7 +1255,6 @@ static int autotune_plan(accel_plan* p)
                     if (base) cs.push_back({wt, 0, 1});
                 }
             }
-            if (c.wubh && !c.f16 && conv_wino_h2w_eligible(c)) cs.push_back({CONV_TILE_WINO_H2W, 0, 0});
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wstemb && !c.f16) cs.push_back({CONV_TILE_STEM_B3, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
@@ -1604,14 +1603,6 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         }
     }
     if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
-    if (const char* hw = getenv("ACCEL_WINO_H2W"); hw && hw[0] == '1') {
-        // A/B switch: every layer the table gives to geometry 43 and that geometry 44 can take (64 -> 64 channels, fp16x2 form) runs on 44
-        for (Op& op : p->ops)
-            if (op.kind == OP_CONV && op.conv.force_tile == CONV_TILE_WINO_B3S && op.conv.wubh && !op.conv.f16 && conv_wino_h2w_eligible(op.conv)) {
-                conv_apply(op.conv, CONV_TILE_WINO_H2W, 0, 0);
-                op.conv.force_tile = CONV_TILE_WINO_H2W;
-            }
-    }
     fuse_stem_pool(p);
     if (use_graph) {
         hipStream_t st = p->m->ctx->stream;

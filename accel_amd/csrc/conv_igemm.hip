@@ -1118,7 +1118,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_WINO_H2W || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS ||
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS ||
            (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5) ||
            (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N);
 }
@@ -1170,7 +1170,6 @@ size_t conv_plan_split(ConvParams& p)
         if (p.ksplit < 2) { p.ksplit = 1; p.kt_per_split = 0; return 0; }
         return (size_t)p.ksplit * p.M * p.Cout_store * sizeof(float);
     }
-    if (tile == CONV_TILE_WINO_H2W) return 0;      // four K steps, one persistent block per CU: no split-K
     if (tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S) {
         // conv_wino_b3.hip: blocks of 64 tiles x 64 channels, K steps of 16 channels; raw partial outputs as for tile 40
         const long blocks = (tile == CONV_TILE_WINO_B3U ? conv_wino_b3u_blocks(p, nullptr) : tile == CONV_TILE_WINO_B3S ? conv_wino_b3s_blocks(p, nullptr) : (long)((p.M / 4 + 63) / 64)) * (long)conv_wino_rows(p.Cout_store) / 64;
@@ -1212,16 +1211,6 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     // +10 = 8-wave / BK-64 experiments (same geometry order)
     if (p.narrow) return launch_conv_narrow(p, st);
     if (p.force_tile == CONV_TILE_WINO) return launch_conv_wino(p, st);
-    if (p.force_tile == CONV_TILE_WINO_H2W) {      // the fp16x2 form only: U's two half planes resident in registers
-        if (!p.wubh || p.f16) return hipErrorInvalidValue;
-        ConvParams q = p;
-        q.wub = p.wubh;
-        q.wub_bytes = p.wub_bytes / 3 * 2;
-        q.scale = p.scale_h2w;
-        q.xs = p.xs_slot;
-        q.f16 = 3;
-        return launch_conv_wino_h2w(q, st);
-    }
     if (p.force_tile == CONV_TILE_WINO_B3 || p.force_tile == CONV_TILE_WINO_B3U || p.force_tile == CONV_TILE_WINO_B3S) {
         ConvParams q = p;
         if (p.wubh && !p.f16) {      // the fp16x2 form: two half planes of U, three products

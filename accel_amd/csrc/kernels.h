@@ -90,7 +90,6 @@ int conv_pick_tile(const ConvParams& p);
 int conv_tile_bk(int tile);
 bool conv_tile_valid(int tile);
 #define CONV_TILE_WINO 40
-#define CONV_TILE_WINO_H2W 44     // fp16x2 Winograd with the transformed weights resident in registers: 64 -> 64 channel layers (conv_wino_h2w.hip)
 #define CONV_TILE_WINO_B3S 43     // 42 with half the block (32 tiles x 64 channels, 4 wavefronts): two blocks per CU (conv_wino_b3s.hip)
 #define CONV_TILE_WINO_B3U 42     // the same with the union of the block's patches loaded once into an LDS copy (tile blocks 8x8 / 4x16 / 2x32)
 #define CONV_TILE_WINO_B3 41      // Winograd F(2x2,3x3) on the bf16 matrix cores, three exact bf16 terms per operand (conv_wino_b3.hip)
@@ -105,8 +104,6 @@ hipError_t launch_conv_wino_b3(const ConvParams& p, hipStream_t st, bool union_l
 long conv_wino_b3u_blocks(const ConvParams& p, int* bhs);
 long conv_wino_b3s_blocks(const ConvParams& p, int* bhs);
 hipError_t launch_conv_wino_b3s(const ConvParams& p, hipStream_t st);
-bool conv_wino_h2w_eligible(const ConvParams& p);
-hipError_t launch_conv_wino_h2w(const ConvParams& p, hipStream_t st);
 hipError_t launch_splitk_reduce(const ConvParams& p, int classes, hipStream_t st);   // sums ws[split][class][M][Cout_store] + epilogue
 #define CONV_TILE_STEM 50
 #define CONV_TILE_STEM_B3 51      // the stem on the bf16 matrix cores, three exact bf16 terms per operand (conv_stem_b3.hip)

@@ -167,7 +167,7 @@ def conv_family(op, dtype="f32"):
         return "conv_narrow_kernel"
     if mode == 1:
         return "conv_f16_kernel"
-    if t in (41, 42, 43, 44):
+    if t in (41, 42, 43):
         return "conv_wino_h2_kernel" if mode == 3 else "conv_wino_b3_kernel"
     if mode == 3 and 76 <= t <= 81:
         return "conv_h2_kernel"

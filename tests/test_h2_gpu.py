@@ -193,35 +193,3 @@ def test_stem_fp16x2_is_as_accurate_as_bf16x3(ctx, monkeypatch):
             err[form] = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=51) - truth).max()) / sc
         print("stem vs float64 at pixel scale %g: bf16x3 %.2e, fp16x2 %.2e" % (xscale, err["b3"], err["h2"]))
         assert err["h2"] <= 3e-6 and err["h2"] <= 1.5 * err["b3"] + 1e-7, (xscale, err)
-
-
-# ---- geometry 44: Winograd in the fp16x2 form with the transformed weights resident in registers (conv_wino_h2w.hip) ----------------------
-@pytest.mark.parametrize("H,W", [(24, 32), (64, 96), (6, 10), (130, 70), (256, 512)])
-def test_weight_resident_winograd_is_bit_identical_to_geometry_43(ctx, H, W, monkeypatch):
-    """same patch path, same V image, same split, same three products in the same order, same output transform: only where the weights
-    live differs.  One tile block, ragged blocks in both directions, more tile blocks than persistent blocks (256 x 512: 1024)"""
-    monkeypatch.setenv("ACCEL_SPLIT", "h2")
-    rng = np.random.default_rng(11)
-    x = np.maximum(rng.standard_normal((1, 64, H, W)), 0).astype(np.float32)
-    w = (rng.standard_normal((64, 64, 3, 3)) * 0.05).astype(np.float32)
-    outs = {}
-    for tile in (43, 44):
-        c = OneConv(ctx, 64, 64, H, W, 3, tile, w)
-        try:
-            assert [o["mode"] for o in c.plan.ops() if o["kind"] == "conv"] == [3]
-            outs[tile] = c(x)
-        finally:
-            c.close()
-    assert np.array_equal(outs[43], outs[44])
-    ref = conv64(x, w, 1)
-    assert float(np.abs(outs[44] - ref).max() / np.abs(ref).max()) <= 3e-6
-
-
-def test_weight_resident_winograd_takes_64_channel_layers_only(ctx, monkeypatch):
-    from accel_amd.runtime import AccelError
-    monkeypatch.setenv("ACCEL_SPLIT", "h2")
-    with pytest.raises(AccelError):
-        OneConv(ctx, 128, 64, 24, 32, 3, 44, rnd(1, 64, 128, 3, 3, scale=0.05))(rnd(2, 1, 128, 24, 32))
-    monkeypatch.setenv("ACCEL_SPLIT", "b3")          # no bf16x3 form of this geometry
-    with pytest.raises(AccelError):
-        OneConv(ctx, 64, 64, 24, 32, 3, 44, rnd(1, 64, 64, 3, 3, scale=0.05))(rnd(2, 1, 64, 24, 32))
