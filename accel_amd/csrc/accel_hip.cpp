@@ -166,6 +166,7 @@ struct accel_plan {
     unsigned* range_flag_dev = nullptr;
     int n_h2 = 0;
     long runs = 0, recal_every = 256;
+    int uncal_retries = 0;
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of the plan (stream-ordered)
     float* ws = nullptr;
     std::vector<std::string> pbuf_reads, pbuf_writes;   // persistent buffers the ops read / write (derived-buffer tracking)
@@ -1544,8 +1545,8 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         HIP_TRY(hipMalloc((void**)&p->range, init.size() * sizeof(float)));
         p->owned.push_back(p->range);
         HIP_TRY(hipMemcpy(p->range, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipHostMalloc((void**)&p->range_flag, sizeof(unsigned), hipHostMallocMapped));
-        *p->range_flag = 0u;
+        HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0] the sticky report, [1] "a layer is still without a range"
+        p->range_flag[0] = p->range_flag[1] = 0u;
         HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
         const char* re = getenv("ACCEL_RECAL_EVERY");
         if (re) p->recal_every = atol(re);
@@ -1639,7 +1640,12 @@ extern "C" int accel_plan_run(accel_plan* p)
     }
     int rc = range_check(p);
     if (rc) return rc;
-    const bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
+    bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
+    // A layer whose input was all zero in a probed run has no range yet (its scale is still 1): the following runs are probed as well until
+    // every layer has one -- at most 8 in a row, a layer that never sees a non-zero pixel must not turn every frame into a probed one
+    if (p->n_h2 && !probed && p->range_flag && p->range_flag[1] && p->uncal_retries < 8) { probed = true; ++p->uncal_retries; }
+    else if (probed) p->uncal_retries = 0;
+    if (probed && p->range_flag) p->range_flag[1] = 0u;
     ++p->runs;
     if (p->gexec && !probed) {
         if (hipGraphLaunch(p->gexec, m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipGraphLaunch failed");

@@ -900,7 +900,10 @@ __global__ void range_set_kernel(float* slot, unsigned* flag, int op_index)
     const unsigned bits = us[2];
     const bool calibrated = us[3] & 1u;
     us[2] = 0u;
-    if (bits == 0u) return;                       // an all-zero input says nothing about the range: the scale stays
+    if (bits == 0u) {                             // an all-zero input says nothing about the range: the scale stays ...
+        if (!calibrated) { flag[1] = 1u; __threadfence_system(); }      // ... and a layer that has none yet asks for the next run to be probed too
+        return;
+    }
     const float a = __uint_as_float(bits);
     const float at_old = a * slot[0];
     if (bits >= 0x7F800000u || (calibrated && at_old >= 61440.f)) { atomicCAS(flag, 0u, (unsigned)op_index + 1u); __threadfence_system(); }

@@ -95,7 +95,8 @@ int accel_plan_op_mode(accel_plan* p, int i, int* mode);
  * probed run has set it yet.  The first accel_plan_run of a plan, and every ACCEL_RECAL_EVERY-th after it (default 256, 0 = never
  * again), measures max |x| of every such convolution's input right before it runs and sets the scale on the device so that the
  * maximum lands in [2^10, 2^11); a probe that finds an input non-finite or past the half range at the scale in force makes the next
- * accel_plan_run fail with ACCEL_ERR_RANGE.  accel_plan_recalibrate makes the next run a probed one.  (No reference counterpart:
+ * accel_plan_run fail with ACCEL_ERR_RANGE.  A layer whose input was all zero when it was probed has no range yet: the runs that follow
+ * are probed too until it has one (at most 8 in a row).  accel_plan_recalibrate makes the next run a probed one.  (No reference counterpart:
  * MXNet computes in fp32; this is the price of running fp32 layers as three half products.) */
 int accel_plan_op_range(accel_plan* p, int i, float* scale, int* calibrated);
 int accel_plan_recalibrate(accel_plan* p);

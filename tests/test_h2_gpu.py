@@ -193,3 +193,26 @@ def test_stem_fp16x2_is_as_accurate_as_bf16x3(ctx, monkeypatch):
             err[form] = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=51) - truth).max()) / sc
         print("stem vs float64 at pixel scale %g: bf16x3 %.2e, fp16x2 %.2e" % (xscale, err["b3"], err["h2"]))
         assert err["h2"] <= 3e-6 and err["h2"] <= 1.5 * err["b3"] + 1e-7, (xscale, err)
+
+
+def test_a_layer_left_without_a_range_is_probed_again(ctx, monkeypatch):
+    """an all-zero input says nothing about the range: the probed first run leaves the layer uncalibrated (scale 1), and the runs that
+    follow are probed as well until it has one -- it does not wait for the periodic re-calibration (here: never)"""
+    monkeypatch.setenv("ACCEL_SPLIT", "h2")
+    monkeypatch.setenv("ACCEL_RECAL_EVERY", "0")
+    cin, cout, H, W = 256, 128, 16, 32
+    w = rnd(3, cout, cin, 1, 1, scale=0.05)
+    x = np.maximum(rnd(4, 1, cin, H, W), 0) * np.float32(1e-4)          # small pixels: at scale 1 the lo terms would be sub-normal halves
+    c = OneConv(ctx, cin, cout, H, W, 1, 81, w)
+    try:
+        assert np.array_equal(c(np.zeros_like(x)), np.zeros((1, cout, H, W), np.float32))
+        assert c.plan.ranges()["c"] == (1.0, False)
+        ref = conv64(x, w, 0)
+        y = c(x)                                                            # probed again: the scale follows THIS frame
+        s, cal = c.plan.ranges()["c"]
+        assert cal and 2.0 ** 10 <= s * float(x.max()) < 2.0 ** 11
+        assert np.abs(y - ref).max() <= 1e-6 * np.abs(ref).max()
+        c(x)
+        assert c.plan.ranges()["c"] == (s, True)                            # and the runs after that are ordinary ones
+    finally:
+        c.close()
