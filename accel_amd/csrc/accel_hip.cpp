@@ -1624,6 +1624,20 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     return 0;
 }
 
+// Is the run that is about to be issued a PROBED one (fp16x2 form: input ranges measured, scales set)?  The first run of a plan, every
+// recal_every-th after it, and -- a layer whose input was all zero in a probed run has no range yet, its scale is still 1 -- the runs that
+// follow a probe which left a layer without one: at most 8 in a row (a layer that never sees a non-zero pixel must not turn every frame
+// into a probed one).  Counts the run.
+static bool next_run_is_probed(accel_plan* p)
+{
+    bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
+    if (p->n_h2 && !probed && p->range_flag && p->range_flag[1] && p->uncal_retries < 8) { probed = true; ++p->uncal_retries; }
+    else if (probed) p->uncal_retries = 0;
+    if (probed && p->range_flag) p->range_flag[1] = 0u;
+    ++p->runs;
+    return probed;
+}
+
 extern "C" int accel_plan_run(accel_plan* p)
 {
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run: plan not finalized");
@@ -1640,13 +1654,7 @@ extern "C" int accel_plan_run(accel_plan* p)
     }
     int rc = range_check(p);
     if (rc) return rc;
-    bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
-    // A layer whose input was all zero in a probed run has no range yet (its scale is still 1): the following runs are probed as well until
-    // every layer has one -- at most 8 in a row, a layer that never sees a non-zero pixel must not turn every frame into a probed one
-    if (p->n_h2 && !probed && p->range_flag && p->range_flag[1] && p->uncal_retries < 8) { probed = true; ++p->uncal_retries; }
-    else if (probed) p->uncal_retries = 0;
-    if (probed && p->range_flag) p->range_flag[1] = 0u;
-    ++p->runs;
+    const bool probed = next_run_is_probed(p);
     if (p->gexec && !probed) {
         if (hipGraphLaunch(p->gexec, m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipGraphLaunch failed");
     } else {
@@ -1748,8 +1756,7 @@ extern "C" int accel_plan_run_serial(accel_plan* p)
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run_serial: plan not finalized");
     int rc = range_check(p);
     if (rc) return rc;
-    const bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));      // as accel_plan_run
-    ++p->runs;
+    const bool probed = next_run_is_probed(p);      // as accel_plan_run
     if ((rc = run_eager(p, probed))) return rc;
     HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
     return range_check(p);
