@@ -138,7 +138,6 @@ struct Op {
     const float* const* slot_b = nullptr;
     size_t nbytes = 0;
     int H = 0, W = 0;
-    bool skip = false;          // a pooling op whose work the stem kernel in front of it does (fuse_stem_pool): nothing is launched
 };
 
 struct accel_plan {
@@ -1011,7 +1010,6 @@ static int finalize_op(accel_plan* p, Op& op)
 
 static int launch_op(accel_plan* p, Op& op)
 {
-    if (op.skip) return 0;
     hipStream_t st = p->m->ctx->stream;
     hipError_t e = hipSuccess;
     switch (op.kind) {
@@ -1262,16 +1260,11 @@ static int autotune_plan(accel_plan* p)
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
-                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5,
-                                        CONV_TILE_B3D, CONV_TILE_B3D + 1, CONV_TILE_B3D + 2, CONV_TILE_B3D + 3, CONV_TILE_B3D + 4, CONV_TILE_B3D + 5};
-            const char* nb3d = getenv("ACCEL_B3D");
+                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
             const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && t < CONV_TILE_B3R && !nb3) continue;
                 if (t >= CONV_TILE_B3R && !c.wb3r) continue;
-                // conv_b3d.hip (both operands by LDS-DMA): measured within +-2 % of the best conv_b3r geometry on every fp32 layer of the
-                // step (profiles/r04_b3d_microbench.log), so it is offered to the tuner only on request (ACCEL_B3D=1); forced geometry ids work
-                if (t >= CONV_TILE_B3D && (!(nb3d && nb3d[0] == '1') || !conv_b3d_eligible(c) || (c.f16 == 1 && t > CONV_TILE_B3D + 3))) continue;
                 if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 if (c.f16 && !(t <= 3 || t == 10 || (c.f16 == 1 && t >= CONV_TILE_B3R && c.wb3r))) continue;
@@ -1495,40 +1488,6 @@ extern "C" int accel_model_add_plan(accel_model* m, const char* role, const char
     return 0;
 }
 
-// The 3x3 / stride-2 max pooling behind a 7x7 / stride-2 stem (the pair the lowering marks: the pool is the conv image's only reader and
-// its output shares no memory with the stem's input) is computed by the stem kernel itself when that kernel runs in its fp16x2 form on
-// geometry 51 (conv_stem_b3.hip, pooled form): the conv image -- 1.07 GB per launch at 8 clips of 1024x2048 -- is neither written nor
-// read.  The pooling op stays in the plan as a skipped entry (accel_plan_profile reports 0 for it).
-// MEASURED (profiles/r04_stem_pool_fusion.log): a tie -- 601-605 us for the fused kernel against 330 + 302 us for the pair at 8 clips of
-// 1024x2048, 628.5 / 628.6 against 630.0 / 628.8 frames/s on the headline.  What the bytes save, the halo costs: 8 conv rows give 3 pooled
-// rows and 64 conv columns 31 pooled ones (1.43x the tiles), and with one block per CU the exchange epilogue (about 800 vector-ALU
-// instructions per wavefront and tile, five barriers) runs beside nothing.  So the pair is fused only on request: ACCEL_STEM_POOL=1.
-static void fuse_stem_pool(accel_plan* p)
-{
-    const char* e = getenv("ACCEL_STEM_POOL");
-    if (!(e && e[0] == '1')) return;
-    for (size_t i = 0; i + 1 < p->ops.size(); ++i) {
-        Op& c = p->ops[i];
-        Op& q = p->ops[i + 1];
-        if (c.kind != OP_CONV || q.kind != OP_POOL || !kv_int(c.kv, "fuse_pool", 0) || !kv_int(q.kv, "fused", 0)) continue;
-        ConvParams& cp = c.conv;
-        const PoolParams& pq = q.pool;
-        if (cp.pool || cp.force_tile != CONV_TILE_STEM_B3 || !cp.wstemh || !cp.xs_slot || cp.f16 || cp.act != 1 || cp.res || cp.y2) continue;
-        if (!pq.is_max || pq.kh != 3 || pq.kw != 3 || pq.sh != 2 || pq.sw != 2 || pq.ph != pq.pw || pq.ph < 0 || pq.ph > 1) continue;
-        if (pq.x != cp.y || q.a.N != c.b.N || q.a.H != cp.Ho || q.a.W != cp.Wo || pq.C4 != 16 || q.a.Cs != cp.yCs) continue;
-        if (2 * (q.b.H - 1) - pq.ph > cp.Ho - 1 || 2 * (q.b.W - 1) - pq.pw > cp.Wo - 1) continue;      // every window starts inside the conv image
-        cp.pool = 1; cp.pool_pad = pq.ph; cp.pool_Ho = q.b.H; cp.pool_Wo = q.b.W;
-        cp.pool_relu = pq.relu; cp.pool_scale = pq.scale; cp.pool_shift = pq.shift;
-        cp.y = q.b.ptr; cp.yCs = q.b.Cs;
-        cp.y_bytes = (unsigned)((((size_t)q.b.N * q.b.H * q.b.W - 1) * q.b.Cs + 64) * 4);
-        q.skip = true;
-        // algorithmic bytes of the pair: the image in, the pooled image out
-        const double conv_img = 4.0 * c.b.N * cp.Ho * cp.Wo * 64, pool_img = 4.0 * q.b.N * q.b.H * q.b.W * 64;
-        if (c.bytes > conv_img) c.bytes += pool_img - conv_img;
-        q.bytes = 0;
-    }
-}
-
 extern "C" int accel_plan_finalize(accel_plan* p)
 {
     if (!p) return fail(ACCEL_ERR_ARG, "accel_plan_finalize: NULL plan");
@@ -1604,7 +1563,6 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         }
     }
     if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
-    fuse_stem_pool(p);
     if (use_graph) {
         hipStream_t st = p->m->ctx->stream;
         // one eager warm-up run: lazy module loading / function attributes must not happen under capture
@@ -1746,7 +1704,7 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
         }
     }
     for (auto& e : ev) hipEventDestroy(e);
-    for (size_t i = 0; i < n; ++i) ms[i] = p->ops[i].skip ? 0.f : (float)(acc[i] / iters);      // a skipped op (fuse_stem_pool) launched nothing
+    for (size_t i = 0; i < n; ++i) ms[i] = (float)(acc[i] / iters);
     return rc;
 }
 

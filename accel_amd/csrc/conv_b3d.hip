@@ -1,23 +1,15 @@
-// bf16x3 implicit GEMM, third generation ("b3d", launch geometries 82-87): the arithmetic of conv_b3r.hip (each fp32 operand split
-// EXACTLY into three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per multiply-add in the same order, fp32 accumulate: results
-// are bit-identical to conv_b3r for the same split-K factor) with BOTH operands brought in by LDS-DMA and the pixel operand split
-// AFTER its fragment read.
+// fp16-MFMA implicit GEMM with BOTH operands brought in by LDS-DMA ("b3d", launch geometries 82-85, 88, 89): the kernel of the f16 mode
+// (plan option dtype=f16, BASELINE config 5) and the only one that reads / writes HALF activation views.
+// (Rounds 4 carried the bf16x3 and fp16x2 forms of the fp32 layers on this staging as well: measured a tie / slower than conv_b3r.hip on
+// every layer of the step -- profiles/r04_b3d_microbench.log, r04_b3d_h2_microbench.log -- and removed in round 5.)
 //
-// What bounded conv_b3r (ablations of fc6 x 8 clips): the loader side -- fp32 pixel loads into registers, the VALU
-// split, three ds_write_b128 per 8 values, weight fragments fetched from L2 by every M half of the block -- cost as much as the
-// multiplication and overlapped with it only in part, because every wavefront alternates between the two roles.
-//
-// Here:
-//   * the pixel tile stays fp32 in LDS and arrives by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write, zero
-//     padding by out-of-range buffer offsets); a wavefront reads the 32 bytes of fp32 its MFMA fragment covers and splits them
-//     in registers.  The wavefronts of a block are laid out along M first, so a pixel row is read and split by ONE wavefront
-//     (WGN = 1) or two, and that split feeds 6 * NI matrix instructions;
-//   * the weight planes (the fragment-ordered copy conv_b3r uses: [class][K step][half step][row][16], one contiguous kilobyte
-//     per 32 rows and half step) arrive by LDS-DMA once per block instead of once per M half, and are read as fragments;
-//   * a stage is ONE half step (16 of K): 4-deep ring, three stages in flight, one raw s_barrier per stage, waits counted
-//     (`vmcnt(L)`), never zero inside the loop.  The fragments of pixel stage k+1 are read and split while the matrix
-//     instructions of stage k run (the barrier of stage k also publishes stage k+1), so the vector ALU work sits beside the
-//     matrix work of the SAME wavefront instead of in a phase of its own;
+//   * the pixel tile arrives by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write, zero padding by out-of-range buffer
+//     offsets): fp32 pixels are read as the 32 bytes a fragment covers and rounded to half in registers; pixels STORED as half (XH) are
+//     the MFMA fragment as the DMA brought it, no conversion at all.  The wavefronts of a block are laid out along M first;
+//   * the weight plane (half-rounded, fragment order [class][K step][half step][row][16]: one contiguous kilobyte per 32 rows and half
+//     step) arrives by LDS-DMA once per block, and is read as fragments;
+//   * a ring stage holds KSUB half steps (16 of K each), NS-deep ring, one raw s_barrier per stage, waits counted (`vmcnt(L)`), never
+//     zero inside the loop; the fragments of the next half step are read while the matrix instructions of the current one run;
 //   * LDS images are lane-linear (the DMA writes base + lane * 16); bank conflicts are removed on the SOURCE side: the 16-byte
 //     slot s of pixel row r holds K quad s ^ ((r >> 2) & 3), the slot of weight row n holds half s ^ ((n >> 3) & 1) -- both
 //     conflict-free for the 16-lane groups that serve a ds_read_b128 (MI355X_MICROARCH.md, LDS).
@@ -32,29 +24,17 @@ typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8d __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_d;
 
-__device__ __forceinline__ void split3_pair_d(float v0, float v1, unsigned& q0, unsigned& q1, unsigned& q2)
-{
-    const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
-    q0 = __builtin_amdgcn_perm(u1, u0, 0x07060302);                       // {top16(v1), top16(v0)}
-    const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), r1 = v1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-    const unsigned s0 = __builtin_bit_cast(unsigned, r0), s1 = __builtin_bit_cast(unsigned, r1);
-    q1 = __builtin_amdgcn_perm(s1, s0, 0x07060302);
-    const float t0 = r0 - __builtin_bit_cast(float, s0 & 0xFFFF0000u), t1 = r1 - __builtin_bit_cast(float, s1 & 0xFFFF0000u);
-    q2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, t1), __builtin_bit_cast(unsigned, t0), 0x07060302);
-}
-
-// NPL = 3: bf16x3; NPL = 1: the fp16-MFMA mode (pixels rounded to half after the fragment read, one plane of half-rounded weights);
-// XH (NPL = 1 only): the pixel operand is STORED as half (ConvParams::x_half): rows of 32 bytes per stage, the fragment is what the
+// NPL = 1 (the only form left): pixels rounded to half after the fragment read, one plane of half-rounded weights;
+// XH: the pixel operand is STORED as half (ConvParams::x_half): rows of 32 bytes per stage, the fragment is what the
 // DMA brought, no conversion at all; the epilogue of the NPL = 1 forms may read a half residual and write half (conv_epilogue_h)
-// KSUB: half steps (16 of K) per ring stage.  The bf16x3 form multiplies 6 * MI * NI matrix instructions per half step and wavefront, the
-// fp16 form MI * NI: with one half step per barrier the fp16 form spent its time at barriers (0.13-0.18 of the fp16 peak on the
+// KSUB: half steps (16 of K) per ring stage.  A half step is MI * NI matrix instructions per wavefront: with one half step per barrier the fp16 form spent its time at barriers (0.13-0.18 of the fp16 peak on the
 // deep-K layers of config 5), so its stages hold 2 or 4 half steps; NS = ring depth (3: two stages in flight, 4: three)
-template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false, int KSUB = 1, int NS = 4>
+template <int BM, int BN, int WGM, int WGN, int NPL = 1, bool XH = false, int KSUB = 1, int NS = 4>
 __global__ __launch_bounds__(64 * WGM * WGN, (NS * KSUB * (BM * (XH ? 32 : 64) + NPL * BN * 32) <= 81920 ? 2 : 1))      // two blocks per CU where the LDS allows it
 void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(!XH || NPL == 1, "half pixel storage belongs to the fp16 form");
+    static_assert(NPL == 1, "the fp16 form is the only one");
     static_assert(NS == 3 || NS == 4, "ring depth");
     constexpr int NW = WGM * WGN;
     constexpr int MI = BM / (WGM * 32), NI = BN / (WGN * 32);
@@ -66,7 +46,6 @@ void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
     // the piece's kind do not depend on the half step): a wavefront issues KSUB * L1 or KSUB * (L1 - 1) pieces per stage
     constexpr int L1 = (NP1 + NW - 1) / NW, LMAX = KSUB * L1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
-    const float xs = (NPL == 2 && p.xs) ? p.xs[0] : 1.f;      // power of two that centres the pixels in the half range (fp16x2 form)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,28 +185,10 @@ void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
                 fa[set][i][0] = *reinterpret_cast<const i32x4*>(st + a_lo[i]);
             } else {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_lo[i]), hi = *reinterpret_cast<const f32x4*>(st + a_hi[i]);
-                if constexpr (NPL == 1) {
-                    f16x8d h;
+                f16x8d h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { h[e] = (_Float16)lo[e]; h[4 + e] = (_Float16)hi[e]; }
-                    fa[set][i][0] = __builtin_bit_cast(i32x4, h);
-                } else if constexpr (NPL == 2) {      // the split of conv_b3r<NPL = 2>: hi = RTNE(v s), lo = RTNE(v s - hi)
-                    f16x8d h, l;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = e < 4 ? lo[e & 3] : hi[e & 3];
-                        h[e] = (_Float16)(v * xs);
-                        l[e] = (_Float16)__builtin_fmaf(v, xs, -(float)h[e]);
-                    }
-                    fa[set][i][0] = __builtin_bit_cast(i32x4, h);
-                    fa[set][i][1] = __builtin_bit_cast(i32x4, l);
-                } else {
-                    unsigned x0, x1, x2;
-                    split3_pair_d(lo[0], lo[1], x0, x1, x2); fa[set][i][0][0] = (int)x0; fa[set][i][1][0] = (int)x1; fa[set][i][2][0] = (int)x2;
-                    split3_pair_d(lo[2], lo[3], x0, x1, x2); fa[set][i][0][1] = (int)x0; fa[set][i][1][1] = (int)x1; fa[set][i][2][1] = (int)x2;
-                    split3_pair_d(hi[0], hi[1], x0, x1, x2); fa[set][i][0][2] = (int)x0; fa[set][i][1][2] = (int)x1; fa[set][i][2][2] = (int)x2;
-                    split3_pair_d(hi[2], hi[3], x0, x1, x2); fa[set][i][0][3] = (int)x0; fa[set][i][1][3] = (int)x1; fa[set][i][2][3] = (int)x2;
-                }
+                for (int e = 0; e < 4; ++e) { h[e] = (_Float16)lo[e]; h[4 + e] = (_Float16)hi[e]; }
+                fa[set][i][0] = __builtin_bit_cast(i32x4, h);
             }
         }
     };
@@ -238,28 +199,9 @@ void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
             i32x4 fb[NPL];
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) fb[pl] = *reinterpret_cast<const i32x4*>(st + b_ad[j] + pl * BN * 32);
-            if constexpr (NPL == 1) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, fa[set][i][0]), __builtin_bit_cast(f16x8d, fb[0]), acc[i][j], 0, 0, 0);
-            } else if constexpr (NPL == 2) {
-                const f16x8d b0 = __builtin_bit_cast(f16x8d, fb[0]), b1 = __builtin_bit_cast(f16x8d, fb[1]);
-                // the two cross terms, then hi * hi (the order of conv_b3r<NPL = 2>), the MI accumulators interleaved
-#define B3D_HTERM(ap, bp)                                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, fa[set][i][ap]), bp, acc[i][j], 0, 0, 0);
-                B3D_HTERM(1, b0) B3D_HTERM(0, b1) B3D_HTERM(0, b0)
-#undef B3D_HTERM
-            } else {
-                const bf16x8d b0 = __builtin_bit_cast(bf16x8d, fb[0]), b1 = __builtin_bit_cast(bf16x8d, fb[1]), b2 = __builtin_bit_cast(bf16x8d, fb[2]);
-                // the six terms, smallest first (the order of conv_b3r), the MI accumulators interleaved so that consecutive matrix
-                // instructions do not wait for each other's result
-#define B3D_TERM(ap, bp)                                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                                   \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8d, fa[set][i][ap]), bp, acc[i][j], 0, 0, 0);
-                B3D_TERM(1, b1) B3D_TERM(0, b2) B3D_TERM(2, b0) B3D_TERM(0, b1) B3D_TERM(1, b0) B3D_TERM(0, b0)
-#undef B3D_TERM
-            }
+            for (int i = 0; i < MI; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, fa[set][i][0]), __builtin_bit_cast(f16x8d, fb[0]), acc[i][j], 0, 0, 0);
         }
     };
 
@@ -293,12 +235,11 @@ void conv_b3d_kernel(ConvParams p, size_t wplane, int rowsB)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may land after the block has given its LDS back
-    if constexpr (NPL == 1) conv_epilogue_h<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
-    else conv_epilogue<MI, NI, WGN, (MI * NI > 4)>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+    conv_epilogue_h<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NPL = 3, bool XH = false, int KSUB = 1, int NS = 4>
+template <int BM, int BN, int WGM, int WGN, int NPL = 1, bool XH = false, int KSUB = 1, int NS = 4>
 static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
 {
     ConvParams p = p0;
@@ -318,8 +259,8 @@ static hipError_t launch_b3d(const ConvParams& p0, hipStream_t st)
 
 bool conv_b3d_eligible(const ConvParams& p) { return p.Cin % 16 == 0 && p.ktab != nullptr; }
 
-// p.w = the fragment-ordered planes (ConvParams::wb3r), p.w_bytes = bytes of one plane of one class; p.f16 == 1: the one-plane fp16 form
-// (with p.x_half: the pixel operand stored as half)
+// p.w = the fragment-ordered half plane (ConvParams::wb3r of an f16-mode layer), p.w_bytes = its bytes per class; p.x_half: the pixel
+// operand stored as half
 hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st)
 {
     if (!conv_b3d_eligible(p)) return hipErrorInvalidValue;
@@ -347,29 +288,5 @@ hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st)
             default: return hipErrorInvalidValue;
         }
     }
-    if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // half storage exists in the fp16 form only
-    if (p.f16 == 3) {
-        // the fp16x2 form (p.w = ConvParams::wh2r, two half planes; p.xs = the layer's range slot): three products per multiply-add,
-        // so a half step carries half the matrix work of the bf16x3 form
-        switch (tile) {
-            case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2, 2>(p, st);                      // 128 KB of LDS, one block per CU
-            case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2, 2>(p, st);                  // 96 KB
-            case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1, 2>(p, st);                  // 64 KB: two blocks per CU
-            case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2, 2>(p, st);
-            case CONV_TILE_B3D + 4: return launch_b3d<256, 256, 8, 1, 2>(p, st);                  // every pixel row split once
-            case CONV_TILE_B3D + 5: return launch_b3d<128, 256, 2, 4, 2>(p, st);
-            case CONV_TILE_B3D + 6: return launch_b3d<128, 64, 4, 1, 2>(p, st);                   // 48 KB: three blocks per CU
-            case CONV_TILE_B3D + 7: return launch_b3d<256, 128, 4, 2, 2>(p, st);                  // 96 KB
-            default: return hipErrorInvalidValue;
-        }
-    }
-    switch (tile) {
-        case CONV_TILE_B3D: return launch_b3d<256, 256, 4, 2>(p, st);          // 8 wavefronts, each 64 x 128: 160 KB of LDS, one block per CU
-        case CONV_TILE_B3D + 1: return launch_b3d<128, 256, 4, 2>(p, st);      // 8 wavefronts, each 32 x 128
-        case CONV_TILE_B3D + 2: return launch_b3d<128, 128, 4, 1>(p, st);      // 4 wavefronts, each 32 x 128: two blocks per CU
-        case CONV_TILE_B3D + 3: return launch_b3d<128, 128, 2, 2>(p, st);      // 4 wavefronts, each 64 x 64
-        case CONV_TILE_B3D + 4: return launch_b3d<256, 256, 8, 1>(p, st);      // 8 wavefronts, each 32 x 256: every pixel row split once
-        case CONV_TILE_B3D + 5: return launch_b3d<128, 256, 2, 4>(p, st);      // 8 wavefronts, each 64 x 64
-        default: return hipErrorInvalidValue;
-    }
+    return hipErrorInvalidValue;      // fp32 layers run on conv_b3r.hip (the bf16x3 / fp16x2 forms of this staging were removed in round 5)
 }

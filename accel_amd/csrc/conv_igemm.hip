@@ -1238,17 +1238,10 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
     const int b3d_tile = (p.force_tile < 0 && (p.x_half || p.y_half || p.res_half)) ? conv_pick_tile(p) : p.force_tile;
     if (b3d_tile >= CONV_TILE_B3D && b3d_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {
-        // conv_b3d.hip: the fragment-ordered planes of conv_b3r (bf16x3) or its one-plane fp16 form, both operands by LDS-DMA
-        if (!p.wb3r || p.f16 == 2) return hipErrorInvalidValue;
+        // conv_b3d.hip: the one-plane fp16 form of an f16-mode layer, both operands by LDS-DMA (fp32 / half views)
+        if (!p.wb3r || p.f16 != 1) return hipErrorInvalidValue;
         ConvParams q = p;
         q.w = static_cast<const float*>(p.wb3r);
-        if (!p.f16 && p.wh2r) {      // the fp16x2 form of the layer: two half planes, three products, the pixel scale of its range slot
-            q.w = static_cast<const float*>(p.wh2r);
-            q.w_bytes = p.w_bytes / 2;
-            q.scale = p.scale_h2;
-            q.xs = p.xs_slot;
-            q.f16 = 3;
-        } else if (!p.f16) { q.w_bytes = p.w_bytes / 2; q.f16 = 2; }
         return launch_conv_b3d(q, b3d_tile, st);
     }
     if (p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;      // no other kernel reads or writes half views

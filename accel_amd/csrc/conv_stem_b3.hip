@@ -30,22 +30,14 @@
 #include "conv_common.h"
 
 namespace {
-constexpr int OTH = 8, OTW = 64;                        // output tile of a block (plain form); the pooled form computes 9 x 64
+constexpr int OTH = 8, OTW = 64;                        // output tile of a block
 constexpr int IRW = 2 * OTW + 5;                         // input window: (2 rows + 5) x 133 pixels
 constexpr int RWS = 408;                                 // floats per staged row (133 x 3 = 399, + the overrun of the last chunk; even: 8-byte reads)
 constexpr int NSTEP = 11;                                // K steps of 16 (22 chunks of 8; chunk 21 is all padding)
 constexpr int WBYTES = NSTEP * 2 * 3 * 64 * 16;          // weight fragments: [step][channel tile][plane][lane][8 bf16]
 constexpr int WBYTES_H2 = NSTEP * 2 * 2 * 64 * 16;       // the fp16x2 form: two half planes
-// conv rows per tile = wavefronts per block.  Pooled form: PR pooled rows need 2 PR + 1 conv rows; 9 wavefronts (PR = 4) leave one SIMD with
-// three wavefronts against two on the others (measured: 650-680 us per launch, twice the plain stem), 8 wavefronts finish PR = 3 pooled rows
-// from 7 of their 8 conv rows
-#ifndef POOL_WAVES
-#define POOL_WAVES 8
-#endif
-constexpr int stem_rows(bool pool) { return pool ? POOL_WAVES : 8; }
-constexpr int stem_win(bool pool) { return (2 * stem_rows(pool) + 5) * RWS; }      // floats per window stage
-constexpr size_t stem_lds(bool h2, bool pool) { return (size_t)(h2 ? WBYTES_H2 : WBYTES) + 2 * stem_win(pool) * sizeof(float) + 256 * sizeof(float); }
-constexpr int PQ = 31, PR = (POOL_WAVES - 1) / 2;                           // pooled columns / rows a block of the pooled form finishes (from 63 x 9 conv pixels)
+constexpr int IRH = 2 * OTH + 5, WIN = IRH * RWS;       // input window rows; floats per window stage
+constexpr size_t stem_lds(bool h2) { return (size_t)(h2 ? WBYTES_H2 : WBYTES) + 2 * WIN * sizeof(float) + 256 * sizeof(float); }
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8sb __attribute__((ext_vector_type(8)));
 
@@ -62,39 +54,27 @@ __device__ __forceinline__ void split3_pair_sb(float v0, float v1, unsigned& q0,
 }
 
 // H2: the fp16x2 form (kernels.h): two half terms per operand, three v_mfma_f32_32x32x16_f16 products per multiply-add
-// POOL: the stem AND the 3x3 / stride-2 max pooling behind it (ConvParams::pool; resnet_v1_101_flownet_deeplab.py:583-585 `pool1`,
-// pad 0 / 'full'; the ResNet-18/34 branch's `pooling0`, pad 1, with the next unit's BatchNorm + ReLU as its epilogue).  The conv image is
-// never written: a block computes 8 x 64 conv pixels, applies BatchNorm + ReLU, takes the horizontal 3-maxima at the even columns
-// across lanes (two whole-wavefront DPP shifts per value), exchanges them through the window stage the K loop has just finished with
-// (one 32-channel half at a time: 8 x 32 x 32 floats), takes the vertical 3-maxima and stores 3 x 31 pooled pixels.  Tiles overlap by
-// two conv rows and two conv columns (recomputed: 8/6 x 64/62 = 1.38 of the matrix work) -- against 1.07 GB written and read again
-// per launch at 8 clips.  Conv positions outside the conv image count as -inf (the clipped windows of both pooling conventions).
-// Opt-in (ACCEL_STEM_POOL=1): measured a tie with the two separate kernels, see accel_hip.cpp fuse_stem_pool.
-template <bool H2, bool POOL>
-__global__ __launch_bounds__(64 * stem_rows(POOL), POOL ? 1 : 2) void conv_stem_b3_kernel(ConvParams p, int tiles_x, int tiles_y, int ntiles)
+template <bool H2>
+__global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int tiles_x, int tiles_y, int ntiles)
 {
     constexpr int NPS = H2 ? 2 : 3;
     constexpr int WB = H2 ? WBYTES_H2 : WBYTES;
-    constexpr int NTHR = 64 * stem_rows(POOL), IRH = 2 * stem_rows(POOL) + 5, WIN = stem_win(POOL);
-    constexpr int TSY = POOL ? 2 * PR : 8, TSX = POOL ? 2 * PQ : OTW;      // conv rows / columns between the origins of neighbouring tiles
+    constexpr int NTHR = 512;
+    constexpr int TSY = OTH, TSX = OTW;      // conv rows / columns between the origins of neighbouring tiles
     const float xs = (H2 && p.xs) ? p.xs[0] : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
     float* win = reinterpret_cast<float*>(smem_sb + WB);           // [2][WIN]
-    float* ssc = win + 2 * WIN;                                    // [64 scale | 64 shift | 64 pool scale | 64 pool shift]
+    float* ssc = win + 2 * WIN;                                    // [64 scale | 64 shift]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kk = lane >> 5;
-    const int pp = POOL ? p.pool_pad : 0;                          // conv row / column in front of the first pooled window
 
     // ---- weights -> LDS (once per persistent block), scale / shift -------------------------------------------------------
     {
         const i32x4* src = reinterpret_cast<const i32x4*>(p.w);
         i32x4* dst = reinterpret_cast<i32x4*>(smem_sb);
         for (int i = tid; i < WB / 16; i += NTHR) dst[i] = src[i];
-        if (tid < 64) {
-            ssc[tid] = p.scale[tid] * xinv; ssc[64 + tid] = p.shift[tid];
-            if constexpr (POOL) { ssc[128 + tid] = p.pool_scale ? p.pool_scale[tid] : 1.f; ssc[192 + tid] = p.pool_scale ? p.pool_shift[tid] : 0.f; }
-        }
+        if (tid < 64) { ssc[tid] = p.scale[tid] * xinv; ssc[64 + tid] = p.shift[tid]; }
     }
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
@@ -105,7 +85,7 @@ __global__ __launch_bounds__(64 * stem_rows(POOL), POOL ? 1 : 2) void conv_stem_
     auto tile_origin = [&](int t, int& n, int& oy0, int& ox0) {
         n = t / (tiles_x * tiles_y);
         const int r0 = t - n * tiles_x * tiles_y, ty = r0 / tiles_x;
-        oy0 = ty * TSY - pp; ox0 = (r0 - ty * tiles_x) * TSX - pp;
+        oy0 = ty * TSY; ox0 = (r0 - ty * tiles_x) * TSX;
     };
     auto load_window = [&](int t) {
         int n, oy0, ox0;
@@ -207,85 +187,6 @@ __global__ __launch_bounds__(64 * stem_rows(POOL), POOL ? 1 : 2) void conv_stem_
         }
         store_window(cur ^ 1);      // nobody reads that stage: its last readers passed the barrier that ended the previous tile
 
-        if constexpr (POOL) {
-            // ---- pooled epilogue ------------------------------------------------------------------------------------------------
-            // this lane: conv pixel (oy0 + wave, ox0 + 32 a + col), channels 32 j + 8 g + 4 kk + e
-            const int oy = oy0 + wave;
-            const bool row_ok = (unsigned)oy < (unsigned)p.Ho;
-            const float ninf = -__builtin_inff();
-            float* X = win + cur * WIN;      // [9 conv rows][32 pooled columns][8 channel quads, rotated by the column][4]
-            const int n_py0 = PR * ((oy0 + pp) / TSY), n_px0 = PQ * ((ox0 + pp) / TSX);      // first pooled row / column of this tile
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wavefront has read its last pixels of stage cur
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the first half has been read by everybody
-                // BatchNorm + ReLU, then max over conv columns lc, lc + 1, lc + 2 (valid at even lc = 32 a + col); 8 channels x 2 pixel tiles at a time
-                const bool ok0 = row_ok && (unsigned)(ox0 + col) < (unsigned)p.Wo, ok1 = row_ok && (unsigned)(ox0 + 32 + col) < (unsigned)p.Wo;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(ssc + j * 32 + 8 * g + 4 * kk);
-                    const f32x4 f4 = *reinterpret_cast<const f32x4*>(ssc + 64 + j * 32 + 8 * g + 4 * kk);
-                    f32x4 h0, h1, hr;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u0 = acc[0][j][4 * g + e] * s4[e] + f4[e], u1 = acc[1][j][4 * g + e] * s4[e] + f4[e];
-                        const float v0 = ok0 ? (leaky ? (u0 > 0.f ? u0 : u0 * p.slope) : fmaxf(u0, floor_)) : ninf;
-                        const float v1 = ok1 ? (leaky ? (u1 > 0.f ? u1 : u1 * p.slope) : fmaxf(u1, floor_)) : ninf;
-                        // lane + 1, lane + 2 by whole-wavefront DPP shifts (pure vector ALU).  The window that starts at column 30 ends in
-                        // column 32 = pixel tile 1, lane 0 of this half: that lane leaves its raw value in the spare slot 31 of the exchange
-                        // image and the vertical pass folds it into pooled column 15
-                        const int b0 = __builtin_bit_cast(int, v0), b1 = __builtin_bit_cast(int, v1);
-                        const int x1 = __builtin_amdgcn_update_dpp(b0, b0, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-                        const int x2 = __builtin_amdgcn_update_dpp(x1, x1, 0x130, 0xF, 0xF, false);
-                        const int y1 = __builtin_amdgcn_update_dpp(b1, b1, 0x130, 0xF, 0xF, false);
-                        const int y2 = __builtin_amdgcn_update_dpp(y1, y1, 0x130, 0xF, 0xF, false);
-                        const float m01 = fmaxf(v0, __builtin_bit_cast(float, x1));
-                        h0[e] = col == 30 ? m01 : fmaxf(m01, __builtin_bit_cast(float, x2));
-                        h1[e] = v1;
-                        hr[e] = fmaxf(fmaxf(v1, __builtin_bit_cast(float, y1)), __builtin_bit_cast(float, y2));
-                    }
-                    if (!(col & 1)) {
-                        const int q0 = col >> 1, q1 = 16 + (col >> 1);
-                        *reinterpret_cast<f32x4*>(X + ((wave * 32 + q0) * 8 + ((2 * g + kk + q0) & 7)) * 4) = h0;
-                        if (col != 30) *reinterpret_cast<f32x4*>(X + ((wave * 32 + q1) * 8 + ((2 * g + kk + q1) & 7)) * 4) = hr;
-                        if (col == 0) *reinterpret_cast<f32x4*>(X + ((wave * 32 + 31) * 8 + ((2 * g + kk + 31) & 7)) * 4) = h1;      // raw column 32
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                // vertical maxima + the pool's own epilogue; thread -> (pooled row, pooled column, channel quad)
-#pragma unroll
-                for (int r = 0; r < (PR * 32 * 8 + NTHR - 1) / NTHR; ++r) {
-                    const int idx = tid + NTHR * r, pr = idx >> 8, q = (idx >> 3) & 31, cq = idx & 7;
-                    if (idx < PR * 32 * 8 && q < PQ) {
-                        const int slot = ((cq + q) & 7) * 4;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(X + (((2 * pr) * 32 + q) * 8) * 4 + slot);
-                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(X + (((2 * pr + 1) * 32 + q) * 8) * 4 + slot);
-                        f32x4 r2 = *reinterpret_cast<const f32x4*>(X + (((2 * pr + 2) * 32 + q) * 8) * 4 + slot);
-                        if (q == 15) {      // its windows end in conv column 32: the raw values in slot 31
-                            const int s31 = ((cq + 31) & 7) * 4;
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                const f32x4 t = *reinterpret_cast<const f32x4*>(X + (((2 * pr + d) * 32 + 31) * 8) * 4 + s31);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) r2[e] = fmaxf(r2[e], t[e]);
-                            }
-                        }
-                        const int c = j * 32 + 4 * cq;
-                        const f32x4 ps = *reinterpret_cast<const f32x4*>(ssc + 128 + c), pf = *reinterpret_cast<const f32x4*>(ssc + 192 + c);
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float m = fmaxf(fmaxf(r0[e], r1[e]), r2[e]);
-                            const float u = p.pool_scale ? m * ps[e] + pf[e] : m;
-                            o[e] = p.pool_relu ? fmaxf(u, 0.f) : u;
-                        }
-                        const int py_ = n_py0 + pr, px_ = n_px0 + q;
-                        const bool ok = py_ < p.pool_Ho && px_ < p.pool_Wo;
-                        buf_store4(yr, ok ? (unsigned)((((n * p.pool_Ho + py_) * p.pool_Wo + px_) * p.yCs + c) * 4) : OOB, o);
-                    }
-                }
-            }
-        } else {
         // ---- epilogue: col = lane & 31 -> pixel, row = (e & 3) + 8 (e >> 2) + 4 kk -> channel: 16-byte stores ----------------
         const int oy = oy0 + wave;
 #pragma unroll
@@ -308,7 +209,6 @@ __global__ __launch_bounds__(64 * stem_rows(POOL), POOL ? 1 : 2) void conv_stem_
                     buf_store4(yr, off0 | (unsigned)(32 * g), o);      // off0 is a multiple of 128 bytes, or all ones
                 }
             }
-        }
         }
         // LDS-only barrier: __syncthreads() would also wait for this tile's output stores to retire
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -368,9 +268,7 @@ hipError_t launch_conv_stem_b3(const ConvParams& p0, hipStream_t st)
     if (!conv_stem_b3_eligible(p) || !p.wstemb) return hipErrorInvalidValue;
     p.w = static_cast<const float*>(p.wstemb);
     const int N = p.M / (p.Ho * p.Wo);
-    const bool pool = p.pool != 0;
-    if (pool && (p.f16 != 3 || p.act != 1 || p.pool_pad < 0 || p.pool_pad > 1)) return hipErrorInvalidValue;      // the pooled form: fp16x2, ReLU in front of the pool
-    const int tiles_x = pool ? (p.pool_Wo + PQ - 1) / PQ : (p.Wo + OTW - 1) / OTW, tiles_y = pool ? (p.pool_Ho + PR - 1) / PR : (p.Ho + OTH - 1) / OTH;
+    const int tiles_x = (p.Wo + OTW - 1) / OTW, tiles_y = (p.Ho + OTH - 1) / OTH;
     const int ntiles = N * tiles_x * tiles_y;
     static int cus = 0;
     if (!cus) {
@@ -380,17 +278,12 @@ hipError_t launch_conv_stem_b3(const ConvParams& p0, hipStream_t st)
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = ntiles < cus ? ntiles : cus;      // 120-135 KB of LDS: one persistent block per CU
-    if (pool) {
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<true, true>), stem_lds(true, true)); e != hipSuccess) return e;
-        hipLaunchKernelGGL((conv_stem_b3_kernel<true, true>), dim3(grid), dim3(64 * stem_rows(true)), stem_lds(true, true), st, p, tiles_x, tiles_y, ntiles);
-        return hipGetLastError();
-    }
     if (p.f16 == 3) {
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<true, false>), stem_lds(true, false)); e != hipSuccess) return e;
-        hipLaunchKernelGGL((conv_stem_b3_kernel<true, false>), dim3(grid), dim3(512), stem_lds(true, false), st, p, tiles_x, tiles_y, ntiles);
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<true>), stem_lds(true)); e != hipSuccess) return e;
+        hipLaunchKernelGGL((conv_stem_b3_kernel<true>), dim3(grid), dim3(512), stem_lds(true), st, p, tiles_x, tiles_y, ntiles);
         return hipGetLastError();
     }
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<false, false>), stem_lds(false, false)); e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_stem_b3_kernel<false, false>), dim3(grid), dim3(512), stem_lds(false, false), st, p, tiles_x, tiles_y, ntiles);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_stem_b3_kernel<false>), stem_lds(false)); e != hipSuccess) return e;
+    hipLaunchKernelGGL((conv_stem_b3_kernel<false>), dim3(grid), dim3(512), stem_lds(false), st, p, tiles_x, tiles_y, ntiles);
     return hipGetLastError();
 }

@@ -622,45 +622,8 @@ hipError_t launch_conv_wino_b3(const ConvParams& p0, hipStream_t st, bool union_
         return hipSuccess;
     };
     hipError_t le;
-    if (union_loader) {
-#ifdef ACCEL_CONV_DIAG
-        static int uvar = -1;
-        if (uvar < 0) { const char* e = getenv("ACCEL_WB3_VARIANT"); uvar = e ? atoi(e) : 0; }
-        switch (uvar) {
-            case 3: le = go(&conv_wino_b3_kernel<3, true>); break;        // no MFMAs
-            case 5: le = go(&conv_wino_b3_kernel<5, true>); break;        // no weight loads
-            case 9: le = go(&conv_wino_b3_kernel<9, true>); break;        // no patch loads, raw copy, transform, V stores
-            case 13: le = go(&conv_wino_b3_kernel<13, true>); break;      // MFMAs + fragment reads + split + barriers
-            case 31: le = go(&conv_wino_b3_kernel<31, true>); break;      // barriers + fragment reads + epilogue only
-            default: le = go(&conv_wino_b3_kernel<0, true>); break;
-        }
-#else
-        le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, true, true>) : go(&conv_wino_b3_kernel<0, true>);
-#endif
-    } else {
-#ifdef ACCEL_CONV_DIAG
-    // timing-only ablations (WRONG results by design; diagnostics build only): ACCEL_WB3_VARIANT = sum of the VAR bits
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("ACCEL_WB3_VARIANT"); var = e ? atoi(e) : 0; }
-    switch (var) {
-        case 1: le = go(&conv_wino_b3_kernel<1>); break;        // channel-block-major block order (correct results)
-        case 3: le = go(&conv_wino_b3_kernel<3>); break;        // no MFMAs
-        case 5: le = go(&conv_wino_b3_kernel<5>); break;        // no weight loads
-        case 9: le = go(&conv_wino_b3_kernel<9>); break;        // no patch loads, no transform, no V stores
-        case 17: le = go(&conv_wino_b3_kernel<17>); break;      // no split
-        case 31: le = go(&conv_wino_b3_kernel<31>); break;      // barriers + fragment reads + epilogue only
-        case 33: le = go(&conv_wino_b3_kernel<33>); break;      // transform + V stores of constant patches (no patch loads)
-        case 65: le = go(&conv_wino_b3_kernel<65>); break;      // patch loads only (no transform, no V stores)
-        case 128: le = go(&conv_wino_b3_kernel<128>); break;    // weight loads non-temporal
-        case 256: le = go(&conv_wino_b3_kernel<256>); break;    // patch loads non-temporal
-        case 1024: le = go(&conv_wino_b3_kernel<1024>); break;  // the 8 tiles of a load instruction fetch the same patch
-        case 2048: le = go(&conv_wino_b3_kernel<2048>); break;  // 4 adjacent lanes on 64 contiguous bytes
-        default: le = go(&conv_wino_b3_kernel<0>); break;
-    }
-#else
-    le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, false, true>) : go(&conv_wino_b3_kernel<0>);
-#endif
-    }
+    if (union_loader) le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, true, true>) : go(&conv_wino_b3_kernel<0, true>);
+    else le = p.f16 == 3 ? go(&conv_wino_b3_kernel<0, false, true>) : go(&conv_wino_b3_kernel<0>);
     if (le != hipSuccess) return le;
     if (p.ksplit > 1) {
         hipError_t e = hipGetLastError();

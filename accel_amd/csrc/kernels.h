@@ -69,11 +69,6 @@ struct ConvParams {
     // calibration), undone in the epilogue.
     const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
     const float* scale_h2; // scale[] with the weight exponents folded in
-    // conv_stem_b3.hip, pooled form: the 3x3 / stride-2 max pooling behind the stem computed by the stem kernel itself; y / yCs are then
-    // the POOLED image (pool_Ho x pool_Wo), Ho / Wo stay the conv image's.  pool_pad: conv rows / columns in front of the first window (0: pad 0,
-    // 'full' convention; 1: pad 1); pool_scale / pool_shift / pool_relu: the pooling op's own BatchNorm + ReLU epilogue (null: none)
-    int pool, pool_pad, pool_Ho, pool_Wo, pool_relu;
-    const float* pool_scale; const float* pool_shift;
     const void* wstemh;    // conv_stem_b3.hip: the stem's fragments as two half planes; null: not offered
     const float* scale_h2s; // scale[] with the stem weights' exponents folded in
     const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
@@ -118,9 +113,8 @@ hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
 #define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);
-#define CONV_TILE_B3D 82                 // conv_b3d.hip (both operands by LDS-DMA, pixels split after the fragment read): 82 = 256x256 / 4x2 wavefronts,
-                                         // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 86 = 256x256 / 8x1, 87 = 128x256 / 2x4;
-                                         // fp16 form only: 88 = 128x64 / 4x1, 89 = 256x128 / 4x2
+#define CONV_TILE_B3D 82                 // conv_b3d.hip (f16-mode layers only; both operands by LDS-DMA, fp32 or half views): 82 = 256x256 / 4x2 wavefronts,
+                                         // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 88 = 128x64 / 4x1, 89 = 256x128 / 4x2 (86 / 87 retired)
 #define CONV_TILE_B3D_N 8
 bool conv_b3d_eligible(const ConvParams& p);
 hipError_t launch_conv_b3d(const ConvParams& p, int tile, hipStream_t st);

@@ -166,8 +166,7 @@ __global__ void pool_max3x3s2_kernel(PoolParams p)
 hipError_t launch_pool(const PoolParams& p, hipStream_t st)
 {
     const long total = (long)p.Ho * p.Wo * p.C4;
-    static const char* pe = getenv("ACCEL_POOL_GENERIC");
-    if (p.is_max && p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2 && !(pe && pe[0] == '1')) {
+    if (p.is_max && p.kh == 3 && p.kw == 3 && p.sh == 2 && p.sw == 2) {
         hipLaunchKernelGGL(pool_max3x3s2_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
         return hipGetLastError();
     }
@@ -301,7 +300,7 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
 // then the 36 corner fetches of the nine taps are in flight together, then nine stores -- the one-tap-per-thread form above has two
 // dependent memory round trips (offset, corners) per 16 bytes written and reached 2.1 TB/s of column writes (round-4 profile: 559-574
 // us for the 1.2 GB column buffer of a res5 layer at 8 clips); same arithmetic per value, same results bit for bit.
-template <int TPT, bool NT = false>      // taps per thread: 9 (all of them) or 3 (one kernel row; blockIdx.y = the row); NT: streaming stores
+template <int TPT, bool NT = false>      // taps per thread: 3 (one kernel row; blockIdx.y = the row); NT: streaming stores
 __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
 {
     const int C4 = p.C / 4;
@@ -322,6 +321,7 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
     const float* b = p.x + zn * p.H * p.W * p.xCs + c4 * 4;
     float4 v1[TPT], v2[TPT], v3[TPT], v4[TPT];
     float w1[TPT], w2[TPT], w3[TPT], w4[TPT];
+    bool inside[TPT];
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
         const int i = (t0 + t) / 3, j = (t0 + t) - 3 * i;
@@ -343,8 +343,10 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
         v2[t] = *reinterpret_cast<const float4*>(b + ((size_t)y0 * p.W + x1) * p.xCs);
         v3[t] = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x0) * p.xCs);
         v4[t] = *reinterpret_cast<const float4*>(b + ((size_t)y1 * p.W + x1) * p.xCs);
-        // a sample outside the image contributes zero (DCN v1): zero weights instead of a branch around the fetches
-        w1[t] = in ? hh * hw : 0.f; w2[t] = in ? hh * lw : 0.f; w3[t] = in ? lh * hw : 0.f; w4[t] = in ? lh * lw : 0.f;
+        // a sample outside the image contributes an exact zero (DCN v1): the fetches stay unconditional (clamped coordinates), the
+        // RESULT is selected below -- zero weights would turn a non-finite feature value at the clamped position into NaN
+        w1[t] = hh * hw; w2[t] = hh * lw; w3[t] = lh * hw; w4[t] = lh * lw;
+        inside[t] = in;
     }
     const size_t at0 = zn * p.Ho * p.Wo * p.colCs + (size_t)pix * p.colCs + c4 * 4;
 #pragma unroll
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
         val.y = w1[t] * v1[t].y + w2[t] * v2[t].y + w3[t] * v3[t].y + w4[t] * v4[t].y;
         val.z = w1[t] * v1[t].z + w2[t] * v2[t].z + w3[t] * v3[t].z + w4[t] * v4[t].z;
         val.w = w1[t] * v1[t].w + w2[t] * v2[t].w + w3[t] * v3[t].w + w4[t] * v4[t].w;
+        if (!inside[t]) val = make_float4(0.f, 0.f, 0.f, 0.f);
         const size_t at = at0 + (size_t)(t0 + t) * p.C;
         if (p.col_half) {
             typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
@@ -369,20 +372,17 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
 
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)
 {
-    const char* one = getenv("ACCEL_DCN_ONE_TAP");       // A/B switch: the one-tap-per-thread kernel
-    if (p.kh == 3 && p.kw == 3 && !(one && one[0] == '1')) {
-        // measured (scripts/microbench/dcn_time.py, res5 of the key plan at 8 clips / of the ResNet-18 branch / at one clip): one tap per
+    if (p.kh == 3 && p.kw == 3) {
+        // measured (scripts/microbench/dcn_time.py, round 4; res5 of the key plan at 8 clips / of the ResNet-18 branch / at one clip): one tap per
         // thread 511 / 137 / 80 us, three taps (one kernel row) 431 / 82 / 55, nine 464 / 99 / 56, three with streaming stores 389 / 80 / 55:
         // a column buffer beyond the 256 MB Infinity Cache is written past the caches, a smaller one stays cached for the GEMM behind it
-        const char* tp = getenv("ACCEL_DCN_TAPS");      // diagnostics: '9' = all taps per thread, 'n' / 'c' = force streaming / cached stores
         const long total = (long)p.Ho * p.Wo * (p.C / 4);
         const size_t col_bytes = (size_t)(p.N > 0 ? p.N : 1) * p.Ho * p.Wo * p.colCs * (p.col_half ? 2 : 4);
-        const bool nt = tp && tp[0] == 'n' ? true : tp && tp[0] == 'c' ? false : col_bytes > ((size_t)256 << 20);
-        if (tp && tp[0] == '9') hipLaunchKernelGGL(dcn_cols9_kernel<9>, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
-        else if (nt) hipLaunchKernelGGL((dcn_cols9_kernel<3, true>), dim3(cdiv(total, 256), 3, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
+        if (col_bytes > ((size_t)256 << 20)) hipLaunchKernelGGL((dcn_cols9_kernel<3, true>), dim3(cdiv(total, 256), 3, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dcn_cols9_kernel<3>, dim3(cdiv(total, 256), 3, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
         return hipGetLastError();
     }
+    // other kernel sizes (none on the Accel graphs; the operator entry point accepts them): one tap per thread
     const long total = (long)p.Ho * p.Wo * p.kh * p.kw * (p.C / 4);
     hipLaunchKernelGGL(dcn_cols_kernel, dim3(cdiv(total, 256), 1, p.N > 0 ? p.N : 1), dim3(256), 0, st, p);
     return hipGetLastError();

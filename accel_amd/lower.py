@@ -542,19 +542,6 @@ class Lowering(object):
         nb, c, ho, wo = self.shape(P)
         _, _, hi, wi = self.shape(x)
         reads = [xin]
-        # A max pooling 3x3/2 straight behind the 7x7/2 stem (its only reader): the library may compute both in the stem kernel and never
-        # write the conv image (conv_stem_b3.hip, pooled form).  Both ops stay in the plan -- the fallback runs them as they are --, the pair
-        # is only marked, and the stem's input stays alive over the pool so that the pooled image never shares memory with it.
-        if self.ops and a["pool_type"] == "max" and a["kernel"] == (3, 3) and a["stride"] == (2, 2) and len(self.consumers(x)) == 1 and (
-                (a["pad"] == (0, 0) and a.get("pooling_convention", "valid") == "full") or
-                (a["pad"] == (1, 1) and a.get("pooling_convention", "valid") == "valid")):
-            pk, pa = self.ops[-1]
-            if (pk == "conv" and pa.get("out") is xin and str(pa.get("k")) == "7,7" and str(pa.get("s")) == "2,2" and str(pa.get("p")) == "3,3"
-                    and int(pa.get("cin", 0)) == 3 and int(pa.get("cout", 0)) == 64 and int(pa.get("act", 0)) == 1
-                    and "res" not in pa and "out2" not in pa and pa.get("mode") == "conv"):
-                pa["fuse_pool"] = 1
-                args["fused"] = 1
-                reads.append(pa["in"])
         self.emit("pool", args, reads, [out], nbytes=4.0 * c * (hi * wi + ho * wo), n=nb)
         for n in [P] + chain:
             self.absorbed.add(id(n))

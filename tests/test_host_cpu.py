@@ -705,33 +705,3 @@ def test_half_storage_set_of_the_f16_mode(demo_cfg, version):
     for kw in (dict(conv_dtype="f16", store_f16=False), dict(conv_dtype="f32", store_f16=True)):
         text, lw = _plan(version, False, H=256, W=512, **kw)
         assert ":h " not in text and not lw.half_bufs
-
-
-@pytest.mark.parametrize("version,key", [("18", True), ("18", False), ("101", False), ("50", False)])
-def test_stem_and_pool_are_marked_as_a_fusable_pair(version, key):
-    """accel_amd/lower.py lower_pool: the 3x3/2 max pooling whose ONLY input is the 7x7/2 stem's image is marked together with it
-    (`fuse_pool=1` / `fused=1`: the library may then run both in the stem kernel, accel_hip.cpp fuse_stem_pool) and -- because the
-    fused kernel reads the frame while it writes the pooled image -- the pooled image must not share arena memory with the stem's input,
-    which an unmarked pair is free to do."""
-    text, _ = _plan(version, key, 256, 512)
-    ops = [l.split() for l in text.split("\n") if l.startswith(("conv ", "pool "))]
-    kv = lambda toks: dict(t.split("=", 1) for t in toks[1:] if "=" in t)
-    convs = {kv(t)["name"]: kv(t) for t in ops if t[0] == "conv"}
-    pools = [kv(t) for t in ops if t[0] == "pool" and kv(t).get("kind") == "max"]
-    stems = [c for c in convs.values() if c.get("k") == "7,7" and c.get("cin") == "3"]
-    assert stems, "no RGB stem in the plan"
-    for c in stems:
-        p = [q for q in pools if q["in"] == c["out"]]
-        assert len(p) == 1 and c.get("fuse_pool") == "1" and p[0].get("fused") == "1", (c["name"], p)
-
-        def span(ref):      # [first byte, last byte) of an arena view "A:off:C:Cs:H:W[:N]"
-            f = ref.split(":")
-            assert f[0] == "A"
-            off, Cs, H, W = int(f[1]), int(f[3]), int(f[4]), int(f[5])
-            n = int(f[6]) if len(f) > 6 else 1
-            return off, off + n * H * W * Cs * 4
-        a0, a1 = span(c["in"])
-        b0, b1 = span(p[0]["out"])
-        assert a1 <= b0 or b1 <= a0, "the pooled image overlaps the stem's input frame"
-    # nothing else is marked
-    assert sum(1 for c in convs.values() if c.get("fuse_pool") == "1") == len(stems)
