@@ -24,6 +24,7 @@
 
 #include "../../include/accel_hip.h"
 #include "kernels.h"
+#include "range.h"
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -138,6 +139,13 @@ struct Op {
     const float* const* slot_b = nullptr;
     size_t nbytes = 0;
     int H = 0, W = 0;
+    // range slots (kernels.h / range.h): ids the lowering gave to the physical buffers this op reads as convolution input (`xr=`) and
+    // writes (`yr=`, `y2r=`); -1: none given.  `measure`: an fp16x2-form convolution whose input tensor is not fully covered by range
+    // epilogues of earlier ops of this plan -- its view is measured by a launch of its own right before it (assign_range_slots)
+    int rs_in = -1, rs_out = -1, rs_out2 = -1;
+    bool measure = false;
+    unsigned* yr = nullptr;     // resolved slots of the outputs (null: nobody needs them); convolutions, pools and the deformable sampler
+    unsigned* y2r = nullptr;    // carry them in their parameter blocks as well
 };
 
 struct accel_plan {
@@ -155,17 +163,16 @@ struct accel_plan {
     int f16 = 0;                    // option dtype=f16: convolutions on the fp16 matrix cores; dtype=bf16x3: 2 (kernels.h)
     // fp32 layers on the matrix cores: split = 1 (default) the fp16x2 form (two half terms per operand, three products), 0 the
     // bf16x3 form (three bf16 terms, six products) -- plan option split=b3|h2, ACCEL_SPLIT=b3|h2.  The fp16x2 form centres every
-    // convolution's pixels in the half range by a power of two kept in `range` (four words per op: {s, 1/s, probed max bits, flags});
-    // a PROBED run (the first run of the plan and every recal_every-th after it) measures the input range of each such
-    // convolution right before it runs and sets the scale on the device (misc.hip range_set_kernel); range_flag is the sticky
-    // host-visible word a probe raises when the range had outgrown the scale.
+    // convolution's pixels in the half range by a power of two that the kernel derives from the RANGE SLOT of its input tensor:
+    // `range` holds n_slots slots of RANGE_WORDS words, zeroed at the start of every run (one memset node of the captured graph) and
+    // raised by the epilogue of whoever writes the tensor -- a run's scales are a function of that run's data, nothing survives it.
+    // range_flag: host-mapped word an fp16x2-form convolution raises when its input's range is not finite (ACCEL_ERR_RANGE).
     int split = 1;
-    float* range = nullptr;
+    unsigned* range = nullptr;
+    int n_slots = 0;
     unsigned* range_flag = nullptr;       // host-mapped
     unsigned* range_flag_dev = nullptr;
     int n_h2 = 0;
-    long runs = 0, recal_every = 256;
-    int uncal_retries = 0;
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of the plan (stream-ordered)
     float* ws = nullptr;
     std::vector<std::string> pbuf_reads, pbuf_writes;   // persistent buffers the ops read / write (derived-buffer tracking)
@@ -317,6 +324,7 @@ static int parse_plan(accel_plan* p, const char* text)
             return fail(ACCEL_ERR_PLAN, "op %s: plans run on one stream (the two-stream lowering was removed, DESIGN.md 7)", op.name.c_str());
         op.flops = kv_f(kv, "flops");
         op.bytes = kv_f(kv, "bytes");
+        op.rs_in = (int)kv_int(kv, "xr", -1); op.rs_out = (int)kv_int(kv, "yr", -1); op.rs_out2 = (int)kv_int(kv, "y2r", -1);
         if (kind == "prep_rgb") op.kind = OP_PREP_RGB;
         else if (kind == "prep_flow") op.kind = OP_PREP_FLOW;
         else if (kind == "conv") op.kind = OP_CONV;
@@ -632,8 +640,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             if ((rc = dev_upload(p, sh.data(), rows * sizeof(float), &dsh))) return rc;
             c.wh2r = dh;
             c.scale_h2 = static_cast<const float*>(dsh);
-            c.xs_slot = p->range + 4 * (size_t)(&op - p->ops.data());
-            ++p->n_h2;
+            ++p->n_h2;      // (the layer's input range slot, ConvParams::xr_slot, is assigned once every op is known: assign_range_slots)
         }
     }
     if (op.c.set) {
@@ -743,7 +750,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 if ((rc = dev_upload(p, ub.data(), ub.size() * sizeof(unsigned short), &db))) return rc;
                 c.wub = db;
                 c.wub_bytes = (unsigned)(ub.size() * sizeof(unsigned short));
-                if (c.xs_slot) {      // fp16x2 form of the layer: the same planes as two half terms
+                if (c.wh2r) {      // fp16x2 form of the layer: the same planes as two half terms
                     std::vector<int> q;
                     conv_wino_b3_pack_h2(w->data.data(), cout, cin, c.wino_rows, ub, q);
                     void *dh = nullptr, *dsh = nullptr;
@@ -781,7 +788,7 @@ static int finalize_conv(accel_plan* p, Op& op)
                 void* dsb = nullptr;
                 if ((rc = dev_upload(p, wb.data(), wb.size() * sizeof(unsigned short), &dsb))) return rc;
                 c.wstemb = dsb;
-                if (c.xs_slot) {      // fp16x2 form of the layer
+                if (c.wh2r) {      // fp16x2 form of the layer
                     std::vector<int> q;
                     conv_stem_b3_pack_h2(w->data.data(), cout, wb, q);
                     void *dh = nullptr, *dsh = nullptr;
@@ -1015,8 +1022,8 @@ static int launch_op(accel_plan* p, Op& op)
     switch (op.kind) {
     case OP_CONV: e = launch_conv_igemm(op.conv, st); break;
     // batch: blockIdx.z = image for the byte movers (fixed stride between images), M = N*Ho*Wo inside the convolution
-    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, op.b.N, st, op.slot_a); break;
-    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, op.c.N, st, op.slot_a, op.slot_b); break;
+    case OP_PREP_RGB: e = launch_prep_rgb(op.a.ptr, op.b.ptr, op.H, op.W, op.p0, op.p1, op.b.N, st, op.slot_a, op.yr); break;
+    case OP_PREP_FLOW: e = launch_prep_flow(op.a.ptr, op.b.ptr, op.c.ptr, op.H, op.W, op.c.N, st, op.slot_a, op.slot_b, op.yr); break;
     case OP_POOL: {
         PoolParams q = op.pool;
         q.N = op.a.N; q.x_img = op.a.img(); q.y_img = op.b.img();
@@ -1025,7 +1032,7 @@ static int launch_op(accel_plan* p, Op& op)
     }
     case OP_WARP:
         e = launch_flow_warp(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.c.ptr, op.c.Cs, op.a.C, op.a.H, op.a.W,
-                             op.d.set ? op.d.ptr : nullptr, op.d.Cs, op.p0, op.a.N, st);
+                             op.d.set ? op.d.ptr : nullptr, op.d.Cs, op.p0, op.a.N, st, op.yr, op.y2r);
         break;
     case OP_DCN_COLS: {
         DcnColsParams q = op.dcn;
@@ -1045,7 +1052,7 @@ static int launch_op(accel_plan* p, Op& op)
         }
         break;
     }
-    case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.N * op.a.H * op.a.W, st); break;
+    case OP_COPY: e = launch_copy_view(op.a.ptr, op.a.Cs, op.b.ptr, op.b.Cs, op.a.C, op.a.N * op.a.H * op.a.W, st, op.yr); break;
     case OP_EXPORT_NCHW:
         for (int n = 0; n < op.a.N && e == hipSuccess; ++n)
             e = launch_nhwc_to_nchw(op.a.ptr + n * op.a.img(), op.a.Cs, op.b.ptr + (size_t)n * op.a.C * op.a.H * op.a.W, op.a.C, op.a.H, op.a.W, st);
@@ -1059,34 +1066,111 @@ static int launch_op(accel_plan* p, Op& op)
     return 0;
 }
 
-// Issues the plan: every op in list order on the context's compute stream (under stream capture this becomes a linear graph).
-// probed: the range of the input of every fp16x2-form convolution is measured right before it runs and its pixel scale set from it
-// (device side, stream-ordered: no host round trip) -- the first run of a plan and its periodic re-calibrations.
-static int run_eager(accel_plan* p, bool probed = false)
+// Issues the plan: the range slots are zeroed, then every op in list order on the context's compute stream (under stream capture this
+// becomes a linear graph).  An fp16x2-form convolution whose input tensor no earlier op of the plan measured (Op::measure) is preceded
+// by the pass that does (misc.hip range_amax_kernel).
+static int launch_measure(accel_plan* p, Op& op)
 {
+    const ConvParams& c = op.conv;
+    hipError_t e = launch_range_amax(c.x, (long)op.a.N * c.H * c.W, c.Cin, c.xCs, const_cast<unsigned*>(c.xr_slot), p->m->ctx->stream);
+    if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "range pass of conv %s failed: %s", op.name.c_str(), hipGetErrorString(e));
+    return 0;
+}
+
+static int run_eager(accel_plan* p)
+{
+    if (p->n_slots && launch_range_clear(p->range, p->n_slots, p->m->ctx->stream) != hipSuccess)
+        return fail(ACCEL_ERR_HIP, "clearing the range slots of plan '%s' failed", p->role.c_str());
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
-        if (probed && op.kind == OP_CONV && op.conv.xs_slot) {
-            const ConvParams& c = op.conv;
-            hipError_t e = launch_range_probe(c.x, (long)op.a.N * c.H * c.W, c.Cin, c.xCs, const_cast<float*>(c.xs_slot), p->range_flag_dev, (int)i, p->m->ctx->stream);
-            if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "range probe of conv %s failed: %s", op.name.c_str(), hipGetErrorString(e));
-        }
-        int rc = launch_op(p, op);
+        int rc = op.measure ? launch_measure(p, op) : 0;
+        if (!rc) rc = launch_op(p, op);
         if (rc) return rc;
     }
     return 0;
 }
 
-// the sticky word a range probe raises (misc.hip range_set_kernel): a loud error instead of silently saturated frames
+// the word an fp16x2-form convolution raises when the range of its input is not finite: a loud error instead of NaN frames
 static int range_check(accel_plan* p)
 {
     if (!p->range_flag || !*p->range_flag) return 0;
-    const unsigned i = *p->range_flag - 1;
-    *p->range_flag = 0u;      // reported once: the probe that raised it has already set the new scale
-    return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s is not finite or outgrew the half range at the scale it was calibrated to (fp16x2 form of the "
-                "fp32 layers: 32x of headroom over the calibrated maximum); frames since the last calibration are not trustworthy.  "
-                "ACCEL_RECAL_EVERY=<runs> (now %ld) re-calibrates more often, ACCEL_SPLIT=b3 selects the range-free bf16x3 form",
-                p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", p->recal_every);
+    const unsigned i = *p->range_flag - 1, bits = p->range_flag[1];
+    *p->range_flag = 0u;      // reported once
+    return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s was not finite in an earlier run (largest |value| seen: bit pattern 0x%08x = %s; fp16x2 "
+                "form of the fp32 layers: the frames of that run are not trustworthy; ACCEL_SPLIT=b3 selects the bf16x3 form, which propagates "
+                "non-finite values like fp32 arithmetic)",
+                p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", bits, bits == 0x7F800000u ? "infinity" : "NaN");
+}
+
+// Range slots (kernels.h, range.h): which tensors need one, who raises it, who has to measure for himself.  Called once every op is
+// finalized (the fp16x2 forms are known) and before anything is launched.
+//   * a slot per physical buffer some convolution WITH an fp16x2 form reads as its input (`xr=<id>` from the lowering; a convolution
+//     of a hand-written plan without an id gets a private slot);
+//   * every op that writes into such a buffer (`yr=` / `y2r=`) and has the range epilogue gets the slot's address;
+//   * a reader is marked `measure` unless at least one earlier op of the plan wrote its buffer and every such writer has the epilogue
+//     (persistent buffers written by another plan or by the host, tensors imported by import_nchw).
+static int assign_range_slots(accel_plan* p)
+{
+    std::map<int, int> slot_of;      // lowering id -> slot index
+    int n = 0;
+    std::vector<int> in_slot(p->ops.size(), -1);
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        Op& op = p->ops[i];
+        if (op.kind != OP_CONV || !(op.conv.wh2r || op.conv.wubh || op.conv.wstemh)) continue;
+        if (op.rs_in < 0) in_slot[i] = n++;
+        else {
+            auto it = slot_of.find(op.rs_in);
+            if (it == slot_of.end()) it = slot_of.insert({op.rs_in, n++}).first;
+            in_slot[i] = it->second;
+        }
+    }
+    p->n_slots = n;
+    if (!n) return 0;
+    HIP_TRY(hipMalloc((void**)&p->range, (size_t)n * RANGE_WORDS * sizeof(unsigned)));
+    p->owned.push_back(p->range);
+    HIP_TRY(hipMemset(p->range, 0, (size_t)n * RANGE_WORDS * sizeof(unsigned)));
+    HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0] first offender's op index + 1, [1] the range it saw
+    p->range_flag[0] = p->range_flag[1] = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
+    auto addr = [&](int id) -> unsigned* {
+        auto it = id < 0 ? slot_of.end() : slot_of.find(id);
+        return it == slot_of.end() ? nullptr : p->range + (size_t)it->second * RANGE_WORDS;
+    };
+    std::vector<int> state(n, 0);      // 0: no writer yet, 1: every writer so far had the epilogue, 2: some writer had not
+    auto wrote = [&](int id, bool has_epilogue) {
+        auto it = id < 0 ? slot_of.end() : slot_of.find(id);
+        if (it == slot_of.end()) return;
+        int& st = state[it->second];
+        st = (has_epilogue && st != 2) ? 1 : 2;
+    };
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        Op& op = p->ops[i];
+        if (in_slot[i] >= 0) {      // reader first: an op never feeds itself
+            ConvParams& c = op.conv;
+            c.xr_slot = p->range + (size_t)in_slot[i] * RANGE_WORDS;
+            c.rflag = p->range_flag_dev;
+            c.op_index = (int)i;
+            op.measure = state[in_slot[i]] != 1;
+        }
+        switch (op.kind) {
+        case OP_CONV:
+            // (half outputs: the lowering keeps a buffer half only if every reader is an f16-mode convolution -- none has an fp16x2 form)
+            op.conv.yr = op.conv.y_half ? nullptr : addr(op.rs_out);
+            op.conv.y2r = addr(op.rs_out2);
+            wrote(op.rs_out, !op.conv.y_half); wrote(op.rs_out2, true);
+            break;
+        case OP_POOL: op.pool.yr = addr(op.rs_out); wrote(op.rs_out, true); break;
+        case OP_DCN_COLS: op.dcn.yr = op.dcn.col_half ? nullptr : addr(op.rs_out); wrote(op.rs_out, !op.dcn.col_half); break;
+        case OP_WARP: case OP_PREP_RGB: case OP_PREP_FLOW: case OP_COPY:
+            op.yr = addr(op.rs_out); op.y2r = addr(op.rs_out2);
+            wrote(op.rs_out, true); wrote(op.rs_out2, true);
+            break;
+        default:
+            wrote(op.rs_out, false); wrote(op.rs_out2, false);    // import_nchw, ...: no epilogue
+            break;
+        }
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1342,6 +1426,10 @@ static int autotune_plan(accel_plan* p)
             // preceding op.  Timing a hot loop of the same launch instead rewards tiles that only win with resident
             // weights and loses ~2 % on the whole plan.
             float best = 1e30f; TuneVal bv = {c.force_tile, 0, 0};
+            if (c.xr_slot) {      // the fp16x2 candidates read the range of the input as it lies there now
+                HIP_TRY(launch_range_clear(const_cast<unsigned*>(c.xr_slot), 1, st));
+                if ((rc = launch_measure(p, op))) break;
+            }
             for (const Cand& k : cands[i]) {
                 ConvParams q = c;
                 conv_apply(q, k.tile, k.split_target, k.no_split);
@@ -1498,22 +1586,11 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         poison(p->arena, p->arena_bytes);
         HIP_TRY(hipMemsetAsync(p->arena, 0, p->arena_bytes, p->m->ctx->stream));
     }
-    {
-        std::vector<float> init(4 * p->ops.size() + 4, 0.f);
-        for (size_t i = 0; i < p->ops.size(); ++i) init[4 * i] = init[4 * i + 1] = 1.f;
-        HIP_TRY(hipMalloc((void**)&p->range, init.size() * sizeof(float)));
-        p->owned.push_back(p->range);
-        HIP_TRY(hipMemcpy(p->range, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0] the sticky report, [1] "a layer is still without a range"
-        p->range_flag[0] = p->range_flag[1] = 0u;
-        HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
-        const char* re = getenv("ACCEL_RECAL_EVERY");
-        if (re) p->recal_every = atol(re);
-    }
     for (Op& op : p->ops) {
         int rc = finalize_op(p, op);
         if (rc) return rc;
     }
+    if (int rc = assign_range_slots(p)) return rc;
     if (p->ws_bytes) {
         HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
         poison(p->ws, p->ws_bytes);
@@ -1582,20 +1659,6 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     return 0;
 }
 
-// Is the run that is about to be issued a PROBED one (fp16x2 form: input ranges measured, scales set)?  The first run of a plan, every
-// recal_every-th after it, and -- a layer whose input was all zero in a probed run has no range yet, its scale is still 1 -- the runs that
-// follow a probe which left a layer without one: at most 8 in a row (a layer that never sees a non-zero pixel must not turn every frame
-// into a probed one).  Counts the run.
-static bool next_run_is_probed(accel_plan* p)
-{
-    bool probed = p->n_h2 && (p->runs == 0 || (p->recal_every > 0 && p->runs % p->recal_every == 0));
-    if (p->n_h2 && !probed && p->range_flag && p->range_flag[1] && p->uncal_retries < 8) { probed = true; ++p->uncal_retries; }
-    else if (probed) p->uncal_retries = 0;
-    if (probed && p->range_flag) p->range_flag[1] = 0u;
-    ++p->runs;
-    return probed;
-}
-
 extern "C" int accel_plan_run(accel_plan* p)
 {
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run: plan not finalized");
@@ -1612,11 +1675,10 @@ extern "C" int accel_plan_run(accel_plan* p)
     }
     int rc = range_check(p);
     if (rc) return rc;
-    const bool probed = next_run_is_probed(p);
-    if (p->gexec && !probed) {
+    if (p->gexec) {
         if (hipGraphLaunch(p->gexec, m->ctx->stream) != hipSuccess) return fail(ACCEL_ERR_HIP, "hipGraphLaunch failed");
     } else {
-        rc = run_eager(p, probed);
+        rc = run_eager(p);
     }
     for (const auto& w : p->pbuf_writes) m->source_written(w);
     for (const auto& w : p->pbuf_writes)
@@ -1658,26 +1720,20 @@ extern "C" int accel_plan_op_mode(accel_plan* p, int i, int* mode)
     return 0;
 }
 
-extern "C" int accel_plan_op_range(accel_plan* p, int i, float* scale, int* calibrated)
+extern "C" int accel_plan_op_range(accel_plan* p, int i, float* scale, int* measured)
 {
     if (!p || !p->finalized || i < 0 || i >= (int)p->ops.size()) return fail(ACCEL_ERR_ARG, "accel_plan_op_range: index out of range");
     const Op& op = p->ops[i];
     if (scale) *scale = 0.f;
-    if (calibrated) *calibrated = 0;
-    if (op.kind != OP_CONV || !op.conv.xs_slot) return 0;
-    float w[4];
+    if (measured) *measured = 0;
+    if (op.kind != OP_CONV || !op.conv.xr_slot) return 0;
+    std::vector<unsigned> w(RANGE_WORDS);
     HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
-    HIP_TRY(hipMemcpy(w, op.conv.xs_slot, sizeof w, hipMemcpyDeviceToHost));
-    if (scale) *scale = w[0];
-    unsigned fl; memcpy(&fl, &w[3], 4);
-    if (calibrated) *calibrated = (int)(fl & 1u);
-    return 0;
-}
-
-extern "C" int accel_plan_recalibrate(accel_plan* p)
-{
-    if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_recalibrate: plan not finalized");
-    p->runs = 0;      // the next run probes
+    HIP_TRY(hipMemcpy(w.data(), op.conv.xr_slot, RANGE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost));
+    unsigned bits = 0u;
+    for (int k = 0; k < RANGE_SUB; ++k) bits = std::max(bits, w[(size_t)k * RANGE_STRIDE]);
+    if (scale) *scale = range_scale(bits).s;
+    if (measured) *measured = bits ? (op.measure ? 2 : 1) : 0;
     return 0;
 }
 
@@ -1691,9 +1747,11 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
     std::vector<double> acc(n, 0.0);
     int rc = 0;
     for (int it = 0; it < iters && !rc; ++it) {
+        if (p->n_slots) HIP_TRY(launch_range_clear(p->range, p->n_slots, st));
         for (size_t i = 0; i < n && !rc; ++i) {
             HIP_TRY(hipEventRecord(ev[2 * i], st));
-            rc = launch_op(p, p->ops[i]);
+            if (p->ops[i].measure) rc = launch_measure(p, p->ops[i]);      // the range pass belongs to the op that needs it
+            if (!rc) rc = launch_op(p, p->ops[i]);
             HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
         }
         HIP_TRY(hipStreamSynchronize(st));
@@ -1714,8 +1772,7 @@ extern "C" int accel_plan_run_serial(accel_plan* p)
     if (!p || !p->finalized) return fail(ACCEL_ERR_ARG, "accel_plan_run_serial: plan not finalized");
     int rc = range_check(p);
     if (rc) return rc;
-    const bool probed = next_run_is_probed(p);      // as accel_plan_run
-    if ((rc = run_eager(p, probed))) return rc;
+    if ((rc = run_eager(p))) return rc;
     HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
     return range_check(p);
 }

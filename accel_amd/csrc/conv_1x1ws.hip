@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(ConvParams p, int mt
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+    unsigned rmax = 0u;
 
     // ---- weights of this column group -> LDS (host layout = LDS image) ----
 #pragma unroll
@@ -179,6 +181,10 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(ConvParams p, int mt
                         o[e] = fmaxf(u, floor_);
                     }
                     buf_store4(yr, rowok[mt][i] ? ooff[mt] + (unsigned)((8 * i * p.yCs + nt * 32) * 4) : OOB, o);
+                    if (p.yr && rowok[mt][i]) {      // range slot of the output (range.h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(o[e]); rmax = b > rmax ? b : rmax; }
+                    }
                 }
             }
 #ifdef WS_TIMING
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_ws_kernel(ConvParams p, int mt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 77 && lane == 0) for (int i = 0; i < 5; ++i) p.y[wave * 8 + i] = (float)tacc[i];
 #endif
+    if (p.yr) range_note_wave(p.yr, rmax, (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));      // once per persistent block and wavefront
 }
 
 template <int K, int BM, int BN>

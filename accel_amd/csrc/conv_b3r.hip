@@ -71,7 +71,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     }
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const int HoWo = p.Ho * p.Wo;
-    const float xs = (NPL == 2 && p.xs) ? p.xs[0] : 1.f;      // power of two that centres the pixels in the half range (fp16x2 form)
+    // fp16x2 form: the power of two that centres the pixels in the half range, from the range slot of the input tensor (range.h)
+    RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
+    if constexpr (NPL == 2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    const float xs = rs.s;
 
     // ---- pixel-tile staging (same row order as conv_igemm_b3_kernel: rows of a group of 8 as 0,4,1,5,2,6,3,7) ------------
     const int t4 = tid / CPR;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
         if constexpr ((ABL & 16) == 0) __syncthreads();
     }
 #undef B3R_FENCE_N
-    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
+    conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo, rs.inv);
 }
 
 template <int BM, int BN, int WGM, int WGN, int ABL = 0, int NPL = 3>

@@ -3,14 +3,18 @@
 #pragma once
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 
 // Shared tail of both conv kernels: split-K partial store or the fused epilogue
 // (scale/shift -> +residual -> activation -> store, optional dual output).
 // RES_PER_J: the residual values are fetched one 32-column block ahead of its stores instead of all at once (tiles with 128
 // accumulator registers per lane cannot hold a second copy of them)
+// xinv: fp16x2 form -- the inverse of the pixel scale the kernel derived from its input's range slot (an exact power of two)
+// Range slots (range.h): where p.yr / p.y2r are set, the largest |value| this wavefront STORED (rows past M and channels past
+// Cout_store do not count) is raised into them at the end.
 template <int MI, int NI, int WGN, bool RES_PER_J = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
-                                              int lane, int py, int px, int HoWo)
+                                              int lane, int py, int px, int HoWo, float xinv = 1.f)
 {
     // ---- output coordinates of this lane's 16*MI accumulator rows ------------------
     // C/D layout of the 32x32 MFMA: col = lane & 31 (-> co), row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -56,7 +60,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // epilogue on 42 us residual layers.  So: every per-channel constant and EVERY residual value is fetched before the
     // first store is issued; after that the epilogue only computes and stores.
     float sc[NI], sf[NI], sc2[NI], sf2[NI];
-    const float xinv = p.xs ? p.xs[1] : 1.f;      // fp16x2 form: undo the pixel exponent (exact power of two)
     bool cok[NI];
     int co[NI];
 #pragma unroll
@@ -86,6 +89,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][j][e];
     }
+    const bool note = p.yr != nullptr, note2 = p.y2 && p.y2r != nullptr;
+    unsigned rmax = 0u, rmax2 = 0u;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         if constexpr (RES_PER_J) {
@@ -104,6 +109,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][e];
             }
         }
+        unsigned mj = 0u, mj2 = 0u;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -121,15 +127,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
                     else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
                     buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co[j]) * 4u : OOB, v[e]);
+                    if (note) { const unsigned b = pix[e] != OOB ? range_abs_bits(v[e]) : 0u; mj = b > mj ? b : mj; }
                 }
                 if (p.y2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, fmaxf(v[e] * sc2[j] + sf2[j], 0.f));
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = fmaxf(v[e] * sc2[j] + sf2[j], 0.f);
+                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, u);
+                        if (note2) { const unsigned b = pix[e] != OOB ? range_abs_bits(u) : 0u; mj2 = b > mj2 ? b : mj2; }
+                    }
                 }
             }
         }
+        rmax = mj > rmax ? mj : rmax; rmax2 = mj2 > rmax2 ? mj2 : rmax2;
     }
+    const unsigned key = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 7u * blockIdx.y;
+    if (note) range_note_wave(p.yr, rmax, key);
+    if (note2) range_note_wave(p.y2r, rmax2, key);
 }
 
 
@@ -142,6 +156,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // the odd lane the pair of the second row as ONE dword -- half as many store instructions as a 2-byte store per value would need,
 // each covering whole 64-byte runs; the half residual is fetched the same way (one dword per lane and row pair) and exchanged back.
 // No dual output (the plan keeps such layers in fp32).
+// Half outputs carry no range slot (the lowering keeps a buffer half only when every reader is an f16-mode convolution, which has no
+// fp16x2 form); an fp32 output written from here (half residual) notes its range like conv_epilogue.
 template <int MI, int NI, int WGN>
 __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
                                                 int lane, int py, int px, int HoWo)
@@ -150,6 +166,8 @@ __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&ac
         conv_epilogue<MI, NI, WGN, true>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
         return;
     }
+    const bool note = p.yr != nullptr && !p.y_half;
+    unsigned rmax = 0u;
     const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
@@ -222,8 +240,10 @@ __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&ac
                 for (int e = 0; e < 16; ++e) {
                     const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
                     buf_store1(yr, (cok && px_ != OOB) ? (px_ * p.yCs + co) * 4u : OOB, v[e]);
+                    if (note) { const unsigned b = (cok && px_ != OOB) ? range_abs_bits(v[e]) : 0u; rmax = b > rmax ? b : rmax; }
                 }
             }
         }
     }
+    if (note) range_note_wave(p.yr, rmax, (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 7u * blockIdx.y);
 }

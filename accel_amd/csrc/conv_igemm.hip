@@ -948,7 +948,10 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
 {
     const int N4 = p.Cout_store / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)classes * p.M * N4) return;
+    // fp16x2 form: the partial sums carry the pixel scale of the launch that wrote them -- the same slot, the same value (range.h)
+    const float xinv = range_prologue(p.xr, nullptr, 0).inv;
+    unsigned rmax = 0u, rmax2 = 0u;
+    if (idx < (long)classes * p.M * N4) {
     const int c4 = (int)(idx % N4);
     const int m = (int)((idx / N4) % p.M);
     const int cls = (int)(idx / ((long)N4 * p.M));
@@ -962,11 +965,12 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
         const int n = m / HoWo, rem = m - n * HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int yy = 2 * oy + (cls >> 1), xx = 2 * ox + (cls & 1);
-        if (yy >= p.yH || xx >= p.yW) return;           // cropped output row / column
-        pix = ((size_t)n * p.yH + yy) * p.yW + xx;
+        if (yy >= p.yH || xx >= p.yW) pix = ~(size_t)0;           // cropped output row / column
+        else pix = ((size_t)n * p.yH + yy) * p.yW + xx;
     }
+    if (pix != ~(size_t)0) {
     const int co = c4 * 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co) * (p.xs ? p.xs[1] : 1.f);      // fp16x2 form: pixel exponent undone
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + co) * xinv;      // fp16x2 form: pixel exponent undone
     const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + co);
     f32x4 v = a * sc + sf;
     typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
@@ -985,17 +989,24 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
         *reinterpret_cast<f16x4s*>(reinterpret_cast<_Float16*>(p.y) + pix * p.yCs + co) = h;
-        return;
-    }
+    } else {
     *reinterpret_cast<f32x4*>(p.y + pix * p.yCs + co) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(v[e]); rmax = b > rmax ? b : rmax; }
     if (p.y2) {
         const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.scale2 + co);
         const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.shift2 + co);
         f32x4 u = v * s2 + b2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = fmaxf(u[e], 0.f);
+        for (int e = 0; e < 4; ++e) { u[e] = fmaxf(u[e], 0.f); const unsigned b = range_abs_bits(u[e]); rmax2 = b > rmax2 ? b : rmax2; }
         *reinterpret_cast<f32x4*>(p.y2 + pix * p.y2Cs + co) = u;
     }
+    }
+    }
+    }
+    // range slots of the outputs (every thread of the block takes part)
+    if (p.yr && !p.y_half) range_note_block(p.yr, rmax, blockIdx.x);
+    if (p.y2 && p.y2r) range_note_block(p.y2r, rmax2, blockIdx.x);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int MID, int ABL = 0, int FAST = 0>
@@ -1217,7 +1228,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
             q.wub = p.wubh;
             q.wub_bytes = p.wub_bytes / 3 * 2;
             q.scale = p.scale_h2w;
-            q.xs = p.xs_slot;
+            q.xr = p.xr_slot;
             q.f16 = 3;
         }
         if (p.force_tile == CONV_TILE_WINO_B3S) return launch_conv_wino_b3s(q, st);
@@ -1229,7 +1240,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
             ConvParams q = p;
             q.wstemb = p.wstemh;
             q.scale = p.scale_h2s;
-            q.xs = p.xs_slot;
+            q.xr = p.xr_slot;
             q.f16 = 3;
             return launch_conv_stem_b3(q, st);
         }
@@ -1258,7 +1269,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         q.w = static_cast<const float*>(p.wh2r);
         q.w_bytes = p.w_bytes / 2;
         q.scale = p.scale_h2;
-        q.xs = p.xs_slot;
+        q.xr = p.xr_slot;
         q.f16 = 3;
         return launch_conv_b3r(q, p.force_tile, st);
     }

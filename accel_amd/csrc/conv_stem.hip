@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 
 namespace {
 constexpr int OTH = 8, OTW = 64;                 // output tile of a block
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f32_kernel(ConvParams p, int
     if (tid < 64) { ssc[tid] = p.scale[tid]; ssc[64 + tid] = p.shift[tid]; }
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
+    unsigned rmax = 0u;
 
     // input window of tile t: NHWC4 pixels, 11 per thread, all in flight together; written to LDS packed to 3 floats
     constexpr int NLD = (IRH * IRW + 255) / 256;
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f32_kernel(ConvParams p, int
                         for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], floor_);       // ReLU (0) or nothing (-inf)
                     }
                     buf_store4(yr, off0 | (unsigned)(32 * g), o);      // off0 is a multiple of 128 bytes, or all ones
+                    if (p.yr && ok) {      // range slot of the output (range.h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(o[e]); rmax = b > rmax ? b : rmax; }
+                    }
                 }
             }
             };
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_f32_kernel(ConvParams p, int
 #ifdef STEM_TIMING
     if (blockIdx.x == 300 && lane == 0) for (int i = 0; i < 5; ++i) p.y[wave * 8 + i] = (float)tacc[i];
 #endif
+    if (p.yr) range_note_wave(p.yr, rmax, (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 }
 
 // layers the stem kernel takes: 7x7 / stride 2 / pad 3 on a 3-channel NHWC4 image, 64 output channels, single output

@@ -28,6 +28,7 @@
 #include <cstdint>
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 
 namespace {
 constexpr int OTH = 8, OTW = 64;                        // output tile of a block
@@ -61,7 +62,11 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
     constexpr int WB = H2 ? WBYTES_H2 : WBYTES;
     constexpr int NTHR = 512;
     constexpr int TSY = OTH, TSX = OTW;      // conv rows / columns between the origins of neighbouring tiles
-    const float xs = (H2 && p.xs) ? p.xs[0] : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;
+    // fp16x2 form: the pixel scale from the range slot of the image tensor (range.h)
+    RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
+    if constexpr (H2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    const float xs = rs.s, xinv = rs.inv;
+    unsigned rmax = 0u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
     float* win = reinterpret_cast<float*>(smem_sb + WB);           // [2][WIN]
     float* ssc = win + 2 * WIN;                                    // [64 scale | 64 shift]
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
                     for (int e = 0; e < 4; ++e) {
                         const float u = acc[a][j][4 * g + e] * s4[e] + f4[e];
                         o[e] = leaky ? (u > 0.f ? u : u * p.slope) : fmaxf(u, floor_);
+                        if (p.yr && ok) { const unsigned b = range_abs_bits(o[e]); rmax = b > rmax ? b : rmax; }
                     }
                     buf_store4(yr, off0 | (unsigned)(32 * g), o);      // off0 is a multiple of 128 bytes, or all ones
                 }
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
         // LDS-only barrier: __syncthreads() would also wait for this tile's output stores to retire
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (p.yr) range_note_wave(p.yr, rmax, (unsigned)(blockIdx.x * 8 + wave));      // once per persistent block and wavefront
 }
 
 bool conv_stem_b3_eligible(const ConvParams& p) { return conv_stem_eligible(p); }

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
         }
         return;
     }
+    unsigned rmax = 0u, rmax2 = 0u;
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI) {
         const bool ok = okS[sI];
@@ -328,6 +330,10 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
                 else if (p.act == 2) v[o][e] = v[o][e] > 0.f ? v[o][e] : v[o][e] * p.slope;
             }
             buf_store4(yr, ok ? (pixS[sI][o] * p.yCs + co) * 4u : OOB, v[o]);
+            if (p.yr && ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(v[o][e]); rmax = b > rmax ? b : rmax; }
+            }
         }
         if (p.y2) {
 #pragma unroll
@@ -336,9 +342,17 @@ __global__ __launch_bounds__(512) void conv_wino_f32_kernel(ConvParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[o][e] * sc2[e] + sf2[e], 0.f);
                 buf_store4(y2r, ok ? (pixS[sI][o] * p.y2Cs + co) * 4u : OOB, u);
+                if (p.y2r && ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(u[e]); rmax2 = b > rmax2 ? b : rmax2; }
+                }
             }
         }
     }
+    // range slots of the outputs (range.h)
+    const unsigned key = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (p.yr) range_note_wave(p.yr, rmax, key);
+    if (p.y2 && p.y2r) range_note_wave(p.y2r, rmax2, key);
 #endif
 }
 

@@ -32,6 +32,7 @@
 #include <vector>
 #include "kernels.h"
 #include "conv_common.h"
+#include "range.h"
 
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
@@ -76,7 +77,11 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NPW = H2 ? 2 : 3;      // planes per operand
-    const float xs = (H2 && p.xs) ? p.xs[0] * 0.25f : 1.f, xinv = (H2 && p.xs) ? p.xs[1] : 1.f;      // the factor 4 is in scale_h2w (host)
+    // fp16x2 form: the pixel scale from the range slot of the input tensor (range.h); the transformed patch B^T d B is up to 4x the
+    // largest pixel, so V is split at a quarter of it (the factor 4 is in scale_h2w, host)
+    RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
+    if constexpr (H2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    const float xs = H2 ? rs.s * 0.25f : 1.f, xinv = rs.inv;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -453,6 +458,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     float* X = smem;                                        // [16][64][32], chunk c of a tile row at slot c ^ (tile & 7)
     const int x_rd = et * 32 + ((ecq ^ (et & 7)) << 2);
     lds_barrier();                                          // every wavefront has read its last fragments
+    unsigned rmax = 0u, rmax2 = 0u;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int co = n0 + jj * 32 + 4 * ecq;
@@ -506,6 +512,10 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
                     else if (p.act == 2) v[o][e] = v[o][e] > 0.f ? v[o][e] : v[o][e] * p.slope;
                 }
                 buf_store4(yr, ok ? (pix[o] * p.yCs + co) * 4u : OOB, v[o]);
+                if (p.yr && ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(v[o][e]); rmax = b > rmax ? b : rmax; }
+                }
             }
             if (p.y2) {
                 const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.scale2 + cc), sf2 = *reinterpret_cast<const f32x4*>(p.shift2 + cc);
@@ -515,10 +525,20 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) u[e] = fmaxf(v[o][e] * sc2[e] + sf2[e], 0.f);
                     buf_store4(y2r, ok ? (pix[o] * p.y2Cs + co) * 4u : OOB, u);
+                    if (p.y2r && ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(u[e]); rmax2 = b > rmax2 ? b : rmax2; }
+                    }
                 }
             }
         }
         if (jj == 0) lds_barrier();                         // round 1 overwrites the image
+    }
+    // range slots of the outputs (range.h): the largest |value| this wavefront stored
+    if (p.ksplit <= 1) {
+        const unsigned key = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        if (p.yr) range_note_wave(p.yr, rmax, key);
+        if (p.y2 && p.y2r) range_note_wave(p.y2r, rmax2, key);
     }
 #endif
 }

@@ -65,16 +65,26 @@ struct ConvParams {
     // fp16x2 form of the bf16x3 kernels ("h2", ConvParams::f16 == 3 inside the launchers): every fp32 operand as hi + lo, two half
     // terms (hi = RTNE(v), lo = RTNE(v - hi): 22-23 significant bits), THREE v_mfma_f32_32x32x16_f16 products per multiply-add
     // (hi*hi + hi*lo + lo*hi), fp32 accumulate.  Operands are centred in the half range by exact powers of two: the weights per
-    // output channel on the host (folded into scale_h2), the pixels by *xs (device scalar pair {s, 1 / s}, set by the plan's range
-    // calibration), undone in the epilogue.
+    // output channel on the host (folded into scale_h2), the pixels by the power of two that the kernel derives IN ITS PROLOGUE from
+    // the largest |pixel| of its input tensor -- measured in the same run by whoever produced that tensor (range slots, below) --
+    // and undoes in the epilogue.  No state survives a run: the scale is a function of the frame's own data.
     const void* wh2r;      // the two half planes in the fragment order of wb3r; null: not offered
     const float* scale_h2; // scale[] with the weight exponents folded in
     const void* wstemh;    // conv_stem_b3.hip: the stem's fragments as two half planes; null: not offered
     const float* scale_h2s; // scale[] with the stem weights' exponents folded in
     const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
     const float* scale_h2w; // scale[] with U's exponents (and the factor 4 of the quarter-scale V split) folded in
-    const float* xs;       // {s, 1 / s}; null = 1.  Set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
-    const float* xs_slot;  // the layer's slot in the plan's range table (accel_plan::range); null: no fp16x2 form
+    // Range slots (range.h): a slot is RANGE_SUB sub-slots of one word, RANGE_STRIDE words apart, zero at the start of every run of
+    // the plan; every kernel that writes a tensor some fp16x2-form convolution reads raises the slot to the largest |value| it
+    // stored (bit pattern of the absolute value, atomicMax: order-independent, so the result is deterministic), the reader takes the
+    // maximum over the sub-slots.  A reader whose input has a writer without that epilogue (or none inside the plan: a persistent
+    // buffer written by another plan or by the host) is preceded by a measuring launch (misc.hip range_amax_kernel) of its view.
+    const unsigned* xr;      // input range slot; set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
+    const unsigned* xr_slot; // the layer's input range slot; null: the layer has no fp16x2 form
+    unsigned* yr;            // range slot of the tensor `y` is (part of); null: no fp16x2-form convolution reads it
+    unsigned* y2r;           // the same for y2
+    unsigned* rflag;         // host-mapped word: an fp16x2-form convolution that finds a non-finite range writes op_index + 1 (ACCEL_ERR_RANGE)
+    int op_index;
     // half activation storage (f16-mode plans; conv_b3d.hip NPL = 1 only): the view is stored as half (2 bytes per element, channel
     // strides in elements, x_bytes / y_bytes / res_bytes in bytes); values are rounded (RTNE) when stored, after the whole epilogue
     int x_half, y_half, res_half;
@@ -129,10 +139,10 @@ size_t conv_plan_split(ConvParams& p);   // sets ksplit/kt_per_split, returns wo
 // NCHW fp32 3xHxW image -> NHWC4 (c3 = 0); optional per-channel scale/shift (bn_data)
 // N images: src image stride 3*H*W, dst image stride 4*H*W
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W,
-                           const float* scale3, const float* shift3, int N, hipStream_t st, const float* const* slot = nullptr);
+                           const float* scale3, const float* shift3, int N, hipStream_t st, const float* const* slot = nullptr, unsigned* yr = nullptr);
 // FlowNet input: avgpool2x2(concat(cur/255, prev/255)) -> NHWC8 at H/2 x W/2 (c6,c7 = 0)
 hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W,
-                            int N, hipStream_t st, const float* const* cur_slot = nullptr, const float* const* prev_slot = nullptr);
+                            int N, hipStream_t st, const float* const* cur_slot = nullptr, const float* const* prev_slot = nullptr, unsigned* yr = nullptr);
 hipError_t launch_set_slot(const void** slot, const void* value, hipStream_t st);
 
 struct PoolParams {
@@ -146,6 +156,7 @@ struct PoolParams {
     int relu;
     int N;                 // images (blockIdx.z); 0 = 1
     size_t x_img, y_img;   // floats between consecutive images
+    unsigned* yr;          // range slot of the output tensor (ConvParams::yr); null: nobody needs it
 };
 hipError_t launch_pool(const PoolParams& p, hipStream_t st);
 
@@ -153,7 +164,7 @@ hipError_t launch_pool(const PoolParams& p, hipStream_t st);
 // optional second output out2 = relu(warped + bias[c]) (bias: C floats)
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs,
                             float* out, int oCs, int C, int H, int W,
-                            float* out2, int o2Cs, const float* bias, int N, hipStream_t st);
+                            float* out2, int o2Cs, const float* bias, int N, hipStream_t st, unsigned* yr = nullptr, unsigned* y2r = nullptr);
 
 struct DcnColsParams {
     const float* x; const float* off; float* col;
@@ -163,6 +174,7 @@ struct DcnColsParams {
     int dg;
     int N;                 // images (blockIdx.z), each H*W*xCs / Ho*Wo*offCs / Ho*Wo*colCs floats apart; 0 = 1
     int col_half;          // the column buffer is stored as half (colCs in elements): values rounded (RTNE) when stored
+    unsigned* yr;          // range slot of the column buffer (ConvParams::yr); null: nobody needs it
 };
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st);
 
@@ -183,11 +195,13 @@ struct ScoreTailParams {
 hipError_t launch_score_tail(const ScoreTailParams& p, hipStream_t st);
 
 hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int H, int W, hipStream_t st);
-hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st);
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st, unsigned* yr = nullptr);
 hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C, int HW, hipStream_t st);
-hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st);
-// range calibration of the fp16x2 form: max |x| of a convolution's input view -> the power-of-two pixel scale of its slot (misc.hip)
-hipError_t launch_range_probe(const float* x, long pixels, int C, int Cs, float* slot, unsigned* flag, int op_index, hipStream_t st);
+hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st, unsigned* yr = nullptr);
+// fp16x2 form: max |x| of a view (pixels x C channels, channel stride Cs) raised into a range slot -- in front of a convolution
+// whose input tensor was not measured by its producers (misc.hip)
+hipError_t launch_range_amax(const float* x, long pixels, int C, int Cs, unsigned* slot, hipStream_t st);
+hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st);      // the slots' sub-slot words back to zero (start of every run)
 hipError_t launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st);      // flat device-to-device copy (one kernel, 16-byte accesses)
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st);   // Cout_store == 4, plain conv, no dual output
 hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,

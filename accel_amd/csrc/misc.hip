@@ -8,8 +8,14 @@
 #include <cstdlib>
 #include <math.h>
 #include "kernels.h"
+#include "range.h"
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Range slots (range.h): every byte mover below whose output some fp16x2-form convolution reads raises that tensor's slot to the
+// largest |value| it stored.  The kernels are written as a body that returns the bit pattern of this thread's largest stored |value|
+// (0: nothing stored) and a wrapper that reduces it over the block -- one atomicMax per block -- so that every thread reaches the barrier.
+#define RANGE_OF4(v) max(max(range_abs_bits((v).x), range_abs_bits((v).y)), max(range_abs_bits((v).z), range_abs_bits((v).w)))
 
 // ---------------------------------------------------------------------------
 // image boundary: NCHW 3xHxW -> NHWC4
@@ -17,11 +23,11 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // (all byte movers below: blockIdx.z = image of the batch, images a fixed stride apart)
 // `slot` (may be null): device address of a pointer the host may redirect to a caller-owned frame between two runs of a captured
 // plan (accel_model_bind_device): the image is then read where it lies, without a copy into the model's input buffer
-__global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW,
-                                const float* scale, const float* shift, const float* const* slot)
+__device__ __forceinline__ unsigned prep_rgb_body(const float* __restrict__ src, float* __restrict__ dst, int HW,
+                                                  const float* scale, const float* shift, const float* const* slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HW) return;
+    if (i >= HW) return 0u;
     if (slot) src = *slot;
     src += (size_t)blockIdx.z * 3 * HW;
     dst += (size_t)blockIdx.z * 4 * HW;
@@ -32,23 +38,30 @@ __global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict
         b = b * scale[2] + shift[2];
     }
     reinterpret_cast<float4*>(dst)[i] = make_float4(r, g, b, 0.f);
+    return max(max(range_abs_bits(r), range_abs_bits(g)), range_abs_bits(b));
+}
+__global__ void prep_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int HW,
+                                const float* scale, const float* shift, const float* const* slot, unsigned* yr)
+{
+    const unsigned m = prep_rgb_body(src, dst, HW, scale, shift, slot);
+    if (yr) range_note_block(yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 hipError_t launch_prep_rgb(const float* src, float* dst, int H, int W, const float* scale3,
-                           const float* shift3, int N, hipStream_t st, const float* const* slot)
+                           const float* shift3, int N, hipStream_t st, const float* const* slot, unsigned* yr)
 {
     const int HW = H * W;
-    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256), 1, N), dim3(256), 0, st, src, dst, HW, scale3, shift3, slot);
+    hipLaunchKernelGGL(prep_rgb_kernel, dim3(cdiv(HW, 256), 1, N), dim3(256), 0, st, src, dst, HW, scale3, shift3, slot, yr);
     return hipGetLastError();
 }
 
 // FlowNet input: Concat(cur/255, prev/255) -> avg pool 2x2/2  (ref get_flownet :1752-1753)
-__global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
-                                 float* __restrict__ dst, int H, int W, const float* const* cur_slot, const float* const* prev_slot)
+__device__ __forceinline__ unsigned prep_flow_body(const float* __restrict__ cur, const float* __restrict__ prev,
+                                                   float* __restrict__ dst, int H, int W, const float* const* cur_slot, const float* const* prev_slot)
 {
     const int Wo = W >> 1, Ho = H >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Ho * Wo) return;
+    if (i >= Ho * Wo) return 0u;
     if (cur_slot) cur = *cur_slot;
     if (prev_slot) prev = *prev_slot;
     const int oy = i / Wo, ox = i - oy * Wo;
@@ -69,24 +82,34 @@ __global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __r
     float4* d = reinterpret_cast<float4*>(dst + (size_t)i * 8);
     d[0] = make_float4(o[0], o[1], o[2], o[3]);
     d[1] = make_float4(o[4], o[5], o[6], o[7]);
+    unsigned m = 0u;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m = max(m, range_abs_bits(o[c]));
+    return m;
+}
+__global__ void prep_flow_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
+                                 float* __restrict__ dst, int H, int W, const float* const* cur_slot, const float* const* prev_slot, unsigned* yr)
+{
+    const unsigned m = prep_flow_body(cur, prev, dst, H, W, cur_slot, prev_slot);
+    if (yr) range_note_block(yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 hipError_t launch_prep_flow(const float* cur, const float* prev, float* dst, int H, int W, int N, hipStream_t st,
-                            const float* const* cur_slot, const float* const* prev_slot)
+                            const float* const* cur_slot, const float* const* prev_slot, unsigned* yr)
 {
     const int n = (H / 2) * (W / 2);
-    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256), 1, N), dim3(256), 0, st, cur, prev, dst, H, W, cur_slot, prev_slot);
+    hipLaunchKernelGGL(prep_flow_kernel, dim3(cdiv(n, 256), 1, N), dim3(256), 0, st, cur, prev, dst, H, W, cur_slot, prev_slot, yr);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // Pooling (max 3x3/2 'full' or 'valid', avg 2x2/2), optional BN+ReLU epilogue
 // ---------------------------------------------------------------------------
-__global__ void pool_kernel(PoolParams p)
+__device__ __forceinline__ unsigned pool_body(const PoolParams& p)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.Ho * p.Wo * p.C4;
-    if (idx >= total) return;
+    if (idx >= total) return 0u;
     const int c4 = (int)(idx % p.C4);
     const int pix = (int)(idx / p.C4);
     const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
@@ -121,15 +144,21 @@ __global__ void pool_kernel(PoolParams p)
         acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
     *reinterpret_cast<float4*>(p.y + blockIdx.z * p.y_img + (size_t)pix * p.yCs + c4 * 4) = acc;
+    return RANGE_OF4(acc);
+}
+__global__ void pool_kernel(PoolParams p)
+{
+    const unsigned m = pool_body(p);
+    if (p.yr) range_note_block(p.yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 // max 3x3 / stride 2 (both conventions: the windows are clipped to the image): the nine taps as nine independent 16-byte loads in
 // flight (the general kernel's loops have run-time bounds: one load, one wait, one maximum at a time).  Same values: a maximum is exact.
-__global__ void pool_max3x3s2_kernel(PoolParams p)
+__device__ __forceinline__ unsigned pool_max3x3s2_body(const PoolParams& p)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)p.Ho * p.Wo * p.C4;
-    if (idx >= total) return;
+    if (idx >= total) return 0u;
     const int c4 = (int)(idx % p.C4);
     const int pix = (int)(idx / p.C4);
     const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
@@ -161,6 +190,12 @@ __global__ void pool_max3x3s2_kernel(PoolParams p)
         acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
     *reinterpret_cast<float4*>(p.y + blockIdx.z * p.y_img + (size_t)pix * p.yCs + c4 * 4) = acc;
+    return RANGE_OF4(acc);
+}
+__global__ void pool_max3x3s2_kernel(PoolParams p)
+{
+    const unsigned m = pool_max3x3s2_body(p);
+    if (p.yr) range_note_block(p.yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 hipError_t launch_pool(const PoolParams& p, hipStream_t st)
@@ -181,10 +216,10 @@ hipError_t launch_pool(const PoolParams& p, hipStream_t st)
 // In NHWC the four taps of a pixel are four contiguous channel rows, so the
 // gather is fully coalesced and needs no cross-lane shuffles.
 // ---------------------------------------------------------------------------
-__global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
-                                 const float* __restrict__ flow, int flCs,
-                                 float* __restrict__ out, int oCs, int C4, int H, int W,
-                                 float* __restrict__ out2, int o2Cs, const float* __restrict__ bias)
+__device__ __forceinline__ void flow_warp_body(const float* __restrict__ feat, int fCs,
+                                               const float* __restrict__ flow, int flCs,
+                                               float* __restrict__ out, int oCs, int C4, int H, int W,
+                                               float* __restrict__ out2, int o2Cs, const float* __restrict__ bias, unsigned& m1, unsigned& m2)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)H * W * C4) return;
@@ -222,21 +257,33 @@ __global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
     o.w = tl.w * wy * wx + tr.w * wy * (1.0f - wx) + bl.w * (1.0f - wy) * wx + br.w * (1.0f - wy) * (1.0f - wx);
     (void)w00; (void)w01; (void)w10; (void)w11;
     *reinterpret_cast<float4*>(out + (size_t)pix * oCs + c4 * 4) = o;
+    m1 = RANGE_OF4(o);
     if (out2) {
         const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
         float4 r;
         r.x = fmaxf(o.x + b.x, 0.f); r.y = fmaxf(o.y + b.y, 0.f); r.z = fmaxf(o.z + b.z, 0.f); r.w = fmaxf(o.w + b.w, 0.f);
         *reinterpret_cast<float4*>(out2 + (size_t)pix * o2Cs + c4 * 4) = r;
+        m2 = RANGE_OF4(r);
     }
+}
+__global__ void flow_warp_kernel(const float* __restrict__ feat, int fCs,
+                                 const float* __restrict__ flow, int flCs,
+                                 float* __restrict__ out, int oCs, int C4, int H, int W,
+                                 float* __restrict__ out2, int o2Cs, const float* __restrict__ bias, unsigned* yr, unsigned* y2r)
+{
+    unsigned m1 = 0u, m2 = 0u;
+    flow_warp_body(feat, fCs, flow, flCs, out, oCs, C4, H, W, out2, o2Cs, bias, m1, m2);
+    if (yr) range_note_block(yr, m1, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
+    if (out2 && y2r) range_note_block(y2r, m2, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int flCs, float* out, int oCs,
-                            int C, int H, int W, float* out2, int o2Cs, const float* bias, int N, hipStream_t st)
+                            int C, int H, int W, float* out2, int o2Cs, const float* bias, int N, hipStream_t st, unsigned* yr, unsigned* y2r)
 {
     const int C4 = C / 4;
     const long total = (long)H * W * C4;
     hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(total, 256), 1, N), dim3(256), 0, st, feat, fCs, flow, flCs,
-                       out, oCs, C4, H, W, out2, o2Cs, bias);
+                       out, oCs, C4, H, W, out2, o2Cs, bias, yr, y2r);
     return hipGetLastError();
 }
 
@@ -245,11 +292,11 @@ hipError_t launch_flow_warp(const float* feat, int fCs, const float* flow, int f
 // orc_deform_im2col): writes col[pixel][tap][ci] (NHWC with 9*C channels) that
 // the implicit-GEMM kernel then contracts as a 1x1 convolution.
 // ---------------------------------------------------------------------------
-__global__ void dcn_cols_kernel(DcnColsParams p)
+__device__ __forceinline__ unsigned dcn_cols_body(const DcnColsParams& p)
 {
     const int C4 = p.C / 4, taps = p.kh * p.kw;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)p.Ho * p.Wo * taps * C4) return;
+    if (idx >= (long)p.Ho * p.Wo * taps * C4) return 0u;
     const int c4 = (int)(idx % C4);
     const int tap = (int)((idx / C4) % taps);
     const int pix = (int)(idx / ((long)C4 * taps));
@@ -294,18 +341,25 @@ __global__ void dcn_cols_kernel(DcnColsParams p)
     } else {
         *reinterpret_cast<float4*>(p.col + at) = val;
     }
+    return RANGE_OF4(val);
+}
+__global__ void dcn_cols_kernel(DcnColsParams p)
+{
+    const unsigned m = dcn_cols_body(p);
+    if (p.yr && !p.col_half) range_note_block(p.yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 // The same function with ONE thread per (pixel, channel quad) walking all kh*kw = 9 taps: the nine offset pairs are fetched first,
 // then the 36 corner fetches of the nine taps are in flight together, then nine stores -- the one-tap-per-thread form above has two
 // dependent memory round trips (offset, corners) per 16 bytes written and reached 2.1 TB/s of column writes (round-4 profile: 559-574
 // us for the 1.2 GB column buffer of a res5 layer at 8 clips); same arithmetic per value, same results bit for bit.
-template <int TPT, bool NT = false>      // taps per thread: 3 (one kernel row; blockIdx.y = the row); NT: streaming stores
-__global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
+template <int TPT, bool NT>      // taps per thread: 3 (one kernel row; blockIdx.y = the row); NT: streaming stores
+__device__ __forceinline__ unsigned dcn_cols9_body(const DcnColsParams& p)
 {
     const int C4 = p.C / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)p.Ho * p.Wo * C4) return;
+    if (idx >= (long)p.Ho * p.Wo * C4) return 0u;
+    unsigned rmax = 0u;
     const int c4 = (int)(idx % C4);
     const int pix = (int)(idx / C4);
     const int t0 = TPT * blockIdx.y;
@@ -357,6 +411,7 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
         val.z = w1[t] * v1[t].z + w2[t] * v2[t].z + w3[t] * v3[t].z + w4[t] * v4[t].z;
         val.w = w1[t] * v1[t].w + w2[t] * v2[t].w + w3[t] * v3[t].w + w4[t] * v4[t].w;
         if (!inside[t]) val = make_float4(0.f, 0.f, 0.f, 0.f);
+        rmax = max(rmax, RANGE_OF4(val));
         const size_t at = at0 + (size_t)(t0 + t) * p.C;
         if (p.col_half) {
             typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
@@ -368,6 +423,13 @@ __global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
             *reinterpret_cast<float4*>(p.col + at) = val;
         }
     }
+    return rmax;
+}
+template <int TPT, bool NT = false>
+__global__ __launch_bounds__(256) void dcn_cols9_kernel(DcnColsParams p)
+{
+    const unsigned m = dcn_cols9_body<TPT, NT>(p);
+    if (p.yr && !p.col_half) range_note_block(p.yr, m, blockIdx.x + 3u * blockIdx.y + 5u * blockIdx.z);
 }
 
 hipError_t launch_dcn_cols(const DcnColsParams& p, hipStream_t st)
@@ -607,8 +669,9 @@ hipError_t launch_nhwc_to_nchw(const float* src, int Cs, float* dst, int C, int 
     return hipGetLastError();
 }
 
-hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st)
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int Cs, int C, int H, int W, hipStream_t st, unsigned* yr)
 {
+    (void)yr;      // (no range epilogue: a reader of an imported tensor measures its view itself, accel_hip.cpp)
     const int HW = H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(Cs, 32)), dim3(32, 8), 0, st, src, dst, Cs, C, HW);
     return hipGetLastError();
@@ -635,20 +698,25 @@ hipError_t launch_argmax_nchw(const float* logits, unsigned char* labels, int C,
 
 // strided NHWC view copy (C floats per pixel, C % 4 == 0): used to persist the
 // propagated feature when it was produced inside a concat buffer
-__global__ void copy_view_kernel(const float* __restrict__ src, int sCs, float* __restrict__ dst, int dCs, int C4, long total)
+__global__ void copy_view_kernel(const float* __restrict__ src, int sCs, float* __restrict__ dst, int dCs, int C4, long total, unsigned* yr)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c4 = (int)(idx % C4);
-    const long pix = idx / C4;
-    *reinterpret_cast<float4*>(dst + pix * dCs + c4 * 4) = *reinterpret_cast<const float4*>(src + pix * sCs + c4 * 4);
+    unsigned m = 0u;
+    if (idx < total) {
+        const int c4 = (int)(idx % C4);
+        const long pix = idx / C4;
+        const float4 v = *reinterpret_cast<const float4*>(src + pix * sCs + c4 * 4);
+        *reinterpret_cast<float4*>(dst + pix * dCs + c4 * 4) = v;
+        m = RANGE_OF4(v);
+    }
+    if (yr) range_note_block(yr, m, blockIdx.x);
 }
 
-hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st)
+hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int C, int HW, hipStream_t st, unsigned* yr)
 {
     const int C4 = (C + 3) / 4;
     const long total = (long)HW * C4;
-    hipLaunchKernelGGL(copy_view_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sCs, dst, dCs, C4, total);
+    hipLaunchKernelGGL(copy_view_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sCs, dst, dCs, C4, total, yr);
     return hipGetLastError();
 }
 
@@ -697,6 +765,7 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
     const float* xn = p.x + (size_t)n * p.H * p.W * p.xCs;
     const int C4 = p.Cin / 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    unsigned rmax = 0u;
     for (int ky = 0; ky < p.kh; ++ky) {
         const int iy = oy * p.sh - p.ph + ky * p.dh;
         if ((unsigned)iy >= (unsigned)p.H) continue;
@@ -731,7 +800,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvParams p)
             else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         }
         *reinterpret_cast<float4*>(p.y + (size_t)m * p.yCs) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(v[e]); rmax = b > rmax ? b : rmax; }
     }
+    if (p.yr) range_note_wave(p.yr, rmax, (unsigned)m);      // range slot of the output (range.h); the wavefront is whole here
 }
 
 // The same layer for its common shape -- 3x3, stride 1, pad 1, at most 2 real output channels (every flow predictor of
@@ -790,6 +862,7 @@ __global__ __launch_bounds__(256) void conv_narrow3x3_kernel(ConvParams p, int s
             acc[t][0] += __shfl_xor(acc[t][0], o);
             acc[t][1] += __shfl_xor(acc[t][1], o);
         }
+    unsigned rmax = 0u;
     if (lane < TX && ox0 + lane < p.Wo) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -804,7 +877,10 @@ __global__ __launch_bounds__(256) void conv_narrow3x3_kernel(ConvParams p, int s
             else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
         }
         *reinterpret_cast<float4*>(p.y + m * p.yCs) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned b = range_abs_bits(v[e]); rmax = b > rmax ? b : rmax; }
     }
+    if (p.yr) range_note_wave(p.yr, rmax, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st)
@@ -867,61 +943,40 @@ hipError_t launch_set_slot(const void** slot, const void* value, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Range calibration of the fp16x2 form (kernels.h, ConvParams::xs).  A slot is four words per convolution:
-//   {s, 1 / s, bits of the largest |pixel| seen by the last probe, flags (bit 0: calibrated)}.
-// range_amax_kernel reduces max |x| over the view a convolution reads (pixels x C channels, channel stride Cs) into the slot
-// (non-negative floats order like their bit patterns, so one atomicMax on the bits; a NaN sorts above infinity and is caught
-// below); range_set_kernel turns it into the power of two that puts the largest pixel into [2^10, 2^11): 32x of headroom to
-// the largest half, full relative precision (two half terms, 22-23 bits) for every pixel down to 2^-13 of the largest and an
-// absolute error of 2^-36 of the largest below that.  The exponent only moves when the probed maximum has left [2^8, 2^12) at the
-// current scale (so that a re-calibration does not change results while the range is stable); a probe that finds the range past
-// the largest half at the scale the frames since the last probe were computed with -- or a non-finite input -- raises the
-// sticky flag the host checks (first offender's op index + 1).
-__global__ void range_amax_kernel(const float* __restrict__ x, long n4, int C4, int Cs, unsigned* __restrict__ slot)
+// Range slot of a VIEW measured by a pass of its own (range.h): in front of an fp16x2-form convolution whose input tensor has a
+// writer without the range epilogue, or none inside the plan (a persistent buffer another plan or the host wrote).
+__global__ __launch_bounds__(256) void range_amax_kernel(const float* __restrict__ x, long n4, int C4, int Cs, unsigned* __restrict__ slot)
 {
-    float m = 0.f;
+    unsigned m = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
         const float4 v = *reinterpret_cast<const float4*>(x + pix * Cs + 4 * c4);
-        // max(|a|, |b|) on the bit patterns keeps a NaN visible (fmaxf would drop it)
-        const unsigned a = max(max(__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu),
-                               max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu));
-        m = __uint_as_float(max(__float_as_uint(m), a));
+        m = max(m, RANGE_OF4(v));
     }
-    unsigned u = __float_as_uint(m);
-    for (int o = 32; o; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o));
-    if ((threadIdx.x & 63) == 0 && u) atomicMax(slot + 2, u);
+    range_note_block(slot, m, blockIdx.x);
 }
 
-__global__ void range_set_kernel(float* slot, unsigned* flag, int op_index)
+// The plan's slots back to zero at the start of a run: the RANGE_SUB words of every slot that are ever written.  (A kernel of its own,
+// not hipMemsetAsync: as a node of a captured graph the runtime's memset filled parts of the table with a stale 16-byte pattern on
+// some replays -- two device pointers alternating, surviving from run to run -- which the readers then took for a NaN range.)
+__global__ __launch_bounds__(256) void range_clear_kernel(unsigned* table, int n_sub)
 {
-    unsigned* us = reinterpret_cast<unsigned*>(slot);
-    const unsigned bits = us[2];
-    const bool calibrated = us[3] & 1u;
-    us[2] = 0u;
-    if (bits == 0u) {                             // an all-zero input says nothing about the range: the scale stays ...
-        if (!calibrated) { flag[1] = 1u; __threadfence_system(); }      // ... and a layer that has none yet asks for the next run to be probed too
-        return;
-    }
-    const float a = __uint_as_float(bits);
-    const float at_old = a * slot[0];
-    if (bits >= 0x7F800000u || (calibrated && at_old >= 61440.f)) { atomicCAS(flag, 0u, (unsigned)op_index + 1u); __threadfence_system(); }
-    if (bits >= 0x7F800000u) return;
-    if (calibrated && at_old >= 256.f && at_old < 4096.f) return;
-    int e = (int)((bits >> 23) & 0xFFu) - 126;    // a = m * 2^e, m in [0.5, 1)  (denormals: e = -126, scale clamped below)
-    e = 11 - e;
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    slot[0] = __uint_as_float((unsigned)(127 + e) << 23);
-    slot[1] = __uint_as_float((unsigned)(127 - e) << 23);
-    us[3] |= 1u;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sub) table[(size_t)(i / RANGE_SUB) * RANGE_WORDS + (size_t)(i % RANGE_SUB) * RANGE_STRIDE] = 0u;
 }
 
-hipError_t launch_range_probe(const float* x, long pixels, int C, int Cs, float* slot, unsigned* flag, int op_index, hipStream_t st)
+hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st)
+{
+    const int n_sub = n_slots * RANGE_SUB;
+    if (n_sub > 0) hipLaunchKernelGGL(range_clear_kernel, dim3(cdiv(n_sub, 256)), dim3(256), 0, st, table, n_sub);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_amax(const float* x, long pixels, int C, int Cs, unsigned* slot, hipStream_t st)
 {
     const long n4 = pixels * (C / 4);
-    const int blocks = (int)std::min<long>(2048, (n4 + 255) / 256);
-    if (blocks > 0) hipLaunchKernelGGL(range_amax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, C / 4, Cs, reinterpret_cast<unsigned*>(slot));
-    hipLaunchKernelGGL(range_set_kernel, dim3(1), dim3(1), 0, st, slot, flag, op_index);
+    const int blocks = (int)std::min<long>(4096, (n4 + 1023) / 1024);
+    if (blocks > 0) hipLaunchKernelGGL(range_amax_kernel, dim3(blocks), dim3(256), 0, st, x, n4, C / 4, Cs, slot);
     return hipGetLastError();
 }

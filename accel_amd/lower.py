@@ -850,8 +850,27 @@ class Lowering(object):
         for name, nbytes in sorted(self.pbufs.items()):
             src = self.derived_bufs.get(name, {}).get("from")
             lines.append("pbuf name=%s bytes=%d%s" % (name, nbytes, " from=%s" % src if src else ""))
+        # Range slots (csrc/range.h, kernels.h ConvParams::xr / yr): every physical buffer gets an id; a convolution names the buffer it
+        # reads (`xr=`), every op the buffers it writes (`yr=`, `y2r=`).  The library gives a slot to the buffers an fp16x2-form convolution
+        # reads and has their writers raise it to the largest |value| they store -- in the run that uses it.
+        pb_ids = {}
+
+        def rid(view):
+            if not isinstance(view, View):
+                return None
+            b = view.buf
+            if b.space == "A":
+                return b.id
+            return 1000000 + pb_ids.setdefault(b.space, len(pb_ids))
+        range_keys = {"conv": (("in", "xr"), ("out", "yr"), ("out2", "y2r")), "pool": (("out", "yr"),), "dcn_cols": (("out", "yr"),),
+                      "warp": (("out", "yr"), ("out2", "y2r")), "prep_rgb": (("dst", "yr"),), "prep_flow": (("dst", "yr"),),
+                      "copy": (("dst", "yr"),)}
         for kind, args in self.ops:
             toks = [kind]
+            for src, key in range_keys.get(kind, ()):
+                r = rid(args.get(src))
+                if r is not None:
+                    toks.append("%s=%d" % (key, r))
             for k, v in args.items():
                 if k.startswith("_"):
                     continue                    # lowering-internal bookkeeping

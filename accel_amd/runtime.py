@@ -54,7 +54,6 @@ def _declare(lib):
         "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_op_mode": [vp, c.c_int, c.POINTER(c.c_int)],
         "accel_plan_op_range": [vp, c.c_int, c.POINTER(c.c_float), c.POINTER(c.c_int)],
-        "accel_plan_recalibrate": [vp],
         "accel_tune_stats": [c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],
@@ -352,21 +351,18 @@ class Plan(object):
         return out
 
     def ranges(self):
-        """fp16x2 form: {op name: (pixel scale, calibrated)} of the convolutions that have one (accel_plan_op_range)"""
+        """fp16x2 form: {op name: (pixel scale of the last run, source)} of the convolutions that have one (accel_plan_op_range);
+        source 0 = no run yet / all-zero input, 1 = raised by the writers' epilogues, 2 = measured by a pass over the input view"""
         out = {}
         kind = ctypes.create_string_buffer(32)
         name = ctypes.create_string_buffer(64)
         for i in range(lib().accel_plan_num_ops(self.handle)):
-            s, cal = ctypes.c_float(), ctypes.c_int()
-            check(lib().accel_plan_op_range(self.handle, i, ctypes.byref(s), ctypes.byref(cal)))
+            s, src = ctypes.c_float(), ctypes.c_int()
+            check(lib().accel_plan_op_range(self.handle, i, ctypes.byref(s), ctypes.byref(src)))
             if s.value:
                 check(lib().accel_plan_op_info(self.handle, i, kind, name, None, None))
-                out[name.value.decode()] = (s.value, bool(cal.value))
+                out[name.value.decode()] = (s.value, int(src.value))
         return out
-
-    def recalibrate(self):
-        """the next run measures the input ranges of the fp16x2-form convolutions again (accel_plan_recalibrate)"""
-        check(lib().accel_plan_recalibrate(self.handle))
 
     def run_serial(self):
         """diagnostics: every op in list order on the context stream (no graph replay), then a host wait"""

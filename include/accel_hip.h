@@ -43,7 +43,7 @@ typedef struct accel_plan accel_plan;     /* one bound graph (key or cur)       
 #define ACCEL_ERR_PLAN (-3)
 #define ACCEL_ERR_PARAM (-4)
 #define ACCEL_ERR_COMM (-5)
-#define ACCEL_ERR_RANGE (-6)   /* fp16x2 form: a convolution input outgrew the calibrated half range (accel_plan_run) */
+#define ACCEL_ERR_RANGE (-6)   /* fp16x2 form: a convolution input was not finite in an earlier run (accel_plan_run) */
 
 const char* accel_last_error(void);
 const char* accel_version(void);
@@ -91,15 +91,14 @@ int accel_plan_op_launch(accel_plan* p, int i, int* tile, int* ksplit, int* narr
  * terms per operand, THREE half products per multiply-add; the default, plan option split=h2); -1 for non-conv ops.  Diagnostic only
  * (bench.py prices families by it). */
 int accel_plan_op_mode(accel_plan* p, int i, int* mode);
-/* fp16x2 form: the power of two conv op i's pixels are multiplied by before the split (0 if the op has no such form) and whether a
- * probed run has set it yet.  The first accel_plan_run of a plan, and every ACCEL_RECAL_EVERY-th after it (default 256, 0 = never
- * again), measures max |x| of every such convolution's input right before it runs and sets the scale on the device so that the
- * maximum lands in [2^10, 2^11); a probe that finds an input non-finite or past the half range at the scale in force makes the next
- * accel_plan_run fail with ACCEL_ERR_RANGE.  A layer whose input was all zero when it was probed has no range yet: the runs that follow
- * are probed too until it has one (at most 8 in a row).  accel_plan_recalibrate makes the next run a probed one.  (No reference counterpart:
- * MXNet computes in fp32; this is the price of running fp32 layers as three half products.) */
-int accel_plan_op_range(accel_plan* p, int i, float* scale, int* calibrated);
-int accel_plan_recalibrate(accel_plan* p);
+/* fp16x2 form: the power of two conv op i's pixels were multiplied by before the split in the plan's LAST run (0 if the op has no such
+ * form) and where the range behind it came from: 0 = no run yet / an all-zero input (scale 1), 1 = raised by the epilogues of the ops
+ * that wrote the tensor, 2 = measured by a pass over the op's input view (tensors written outside the plan).  The scale is derived by
+ * the convolution itself, in its prologue, from the largest |value| of its input tensor in THAT run (the largest lands in
+ * [2^13, 2^14)): a plan run is a pure function of its inputs and parameters, like an executor forward of the reference
+ * (dff_deeplab/core/module.py:1011-1044) -- nothing is calibrated, nothing survives a run.  A convolution that finds the range of its
+ * input non-finite makes the NEXT accel_plan_run fail with ACCEL_ERR_RANGE (once).  Diagnostic only. */
+int accel_plan_op_range(accel_plan* p, int i, float* scale, int* source);
 /* Launch geometries are REPRODUCIBLE: decisions come from the table shipped beside the library (tune/gfx950.tune, covers
  * the BASELINE workloads) or from the user's table ($ACCEL_TUNE_CACHE, else ~/.cache/accel_amd/gfx950.tune); a shape in
  * neither is timed once and appended to the user's table.  Counters of this process: decisions replayed, decisions

@@ -1,9 +1,10 @@
 """The fp16x2 form of the fp32 layers (kernels.h ConvParams::wh2r / wubh; conv_b3r.hip NPL = 2, conv_wino_b3*.hip H2): every fp32
 operand as two half terms, three fp16 MFMA products per multiply-add, operands centred in the half range by exact powers of two --
-the weights per output channel on the host, the pixels by the scale a probed run measures (accel_plan_op_range).
+the weights per output channel on the host, the pixels by the scale the convolution derives in its prologue from the range slot of its
+input tensor, raised IN THE SAME RUN by whoever wrote that tensor (csrc/range.h; accel_plan_op_range).
 Bars: against float64 the form must be as accurate as the bf16x3 form it replaces (both are at fp32 accumulation noise), whatever the
-scale of the data; the calibration must put the largest pixel into [2^10, 2^11), keep its scale while the range is stable, move it
-when the range moves, and report a range that outgrew the scale."""
+scale of the data; the scale must put the largest pixel of THIS run into [2^13, 2^14) whatever the runs before it looked like (a plan
+run is a pure function of its inputs: no calibration, no history), and a non-finite input must be reported."""
 import os
 
 import numpy as np
@@ -105,70 +106,90 @@ def test_b3r_geometries_agree_bit_for_bit_in_the_fp16x2_form(ctx, monkeypatch):
         assert np.array_equal(o, outs[0])
 
 
-def test_calibration_scale_hysteresis_and_report(ctx, monkeypatch):
+def test_the_scale_follows_every_run_and_no_run_remembers_another(ctx, monkeypatch):
+    """One bound plan, inputs whose range jumps by 1e-3 ... 1e6 between consecutive runs: every run at full accuracy, the scale a
+    function of that run's input alone, the same input bit-identical whatever came before it; non-finite inputs reported."""
     monkeypatch.setenv("ACCEL_SPLIT", "h2")
-    monkeypatch.setenv("ACCEL_RECAL_EVERY", "0")          # only the first run and explicit re-calibrations probe
     cin, cout, H, W = 256, 128, 16, 32
     w = rnd(3, cout, cin, 1, 1, scale=0.05)
     x = np.maximum(rnd(4, 1, cin, H, W), 0)
     c = OneConv(ctx, cin, cout, H, W, 1, 81, w)
     try:
-        assert c.plan.ranges() == {"c": (1.0, False)}                      # before the first run
+        assert c.plan.ranges() == {"c": (1.0, 0)}                          # before the first run
         ref = conv64(x, w, 0)
         tol = 1e-6 * np.abs(ref).max()
-        assert np.abs(c(x) - ref).max() <= tol
-        s0, cal = c.plan.ranges()["c"]
+        first = c(x)
+        assert np.abs(first - ref).max() <= tol
+        s0, src = c.plan.ranges()["c"]
         amax = float(x.max())
-        assert cal and 2.0 ** 10 <= s0 * amax < 2.0 ** 11 and np.log2(s0) == int(np.log2(s0))
-        # a range that moved by 1.5x keeps the scale even when probed (inside the hysteresis window [2^8, 2^12))
-        c.plan.recalibrate()
-        assert np.abs(c(1.5 * x) - 1.5 * ref).max() <= 1.5 * tol and c.plan.ranges()["c"][0] == s0
-        # 1/1000 of the range, not re-calibrated: still computed (lo terms lose bits -- the reason the probe exists) ...
-        y = c(1e-3 * x)
-        assert np.abs(y - 1e-3 * ref).max() <= 2e-3 * np.abs(ref).max() * 1e-3
-        # ... and with a probe the scale follows and the result is at full accuracy again
-        c.plan.recalibrate()
-        assert np.abs(c(1e-3 * x) - 1e-3 * ref).max() <= 1e-3 * tol
-        s1 = c.plan.ranges()["c"][0]
-        assert 2.0 ** 10 <= s1 * amax * 1e-3 < 2.0 ** 11
-        # the range outgrows the scale in force (x 1e6 since the last probe): the probe corrects the scale for THIS frame and the
-        # library reports that the frames since the last probe may have saturated -- once
-        c.plan.recalibrate()
-        y = c(1e3 * x)
-        assert np.abs(y - 1e3 * ref).max() <= 1e3 * tol
-        with pytest.raises(runtime.AccelError, match="outgrew the half range"):
-            c(1e3 * x)
-        assert np.abs(c(1e3 * x) - 1e3 * ref).max() <= 1e3 * tol              # reported once; the plan keeps working
-        # a non-finite input is reported as well
-        bad = x.copy(); bad[0, 3, 2, 1] = np.nan
-        c.plan.recalibrate()
+        assert src == 2 and 2.0 ** 13 <= s0 * amax < 2.0 ** 14 and np.log2(s0) == int(np.log2(s0))      # (import_nchw has no epilogue: measured)
+        for f in (1.5, 1e-3, 1e3, 1e-6, 1e6 * 1e-6, 100.0, 1.0):          # consecutive runs, no re-binding, ranges jumping both ways
+            y = c(np.float32(f) * x)
+            s, _ = c.plan.ranges()["c"]
+            assert 2.0 ** 13 <= s * amax * np.float32(f) < 2.0 ** 14, (f, s)
+            assert np.abs(y - f * ref).max() <= f * tol * 1.01, f
+        assert np.array_equal(c(x), first)                                  # the same frame after another history: bit-identical
+        assert np.array_equal(c(np.zeros_like(x)), np.zeros((1, cout, H, W), np.float32))
+        assert c.plan.ranges()["c"] == (1.0, 0)                             # an all-zero input: scale 1
+        assert np.array_equal(c(x), first)
+        # a non-finite input is reported by the next run (once); the plan keeps working
+        bad = x.copy(); bad[0, 3, 2, 1] = np.inf
         c(bad)
         with pytest.raises(runtime.AccelError, match="not finite"):
             c(x)
+        assert np.array_equal(c(x), first)
     finally:
         c.close()
 
 
-def test_periodic_recalibration(ctx, monkeypatch):
-    """ACCEL_RECAL_EVERY = 3: runs 0, 3, 6 ... of a plan are probed"""
+def _two_convs(ctx, cin, cmid, cout, H, W, w1, w2, tile2, graph=False):
+    """conv 1x1 (fp32 geometry 0, ReLU) -> conv 1x1 (forced fp16x2 geometry): the second one's range comes from the first one's epilogue"""
+    m = runtime.Model(ctx)
+    al = lambda b: (b + 255) // 256 * 256
+    o_m, o_y = al(H * W * cin * 4), al(H * W * cin * 4) + al(H * W * cmid * 4)
+    m.set_param("w1_weight", w1); m.set_param("w2_weight", w2)
+    t = ("" if graph else "option graph=0\n") + "option tune=0\narena bytes=%d\npbuf name=x bytes=%d\npbuf name=y bytes=%d\n" % (
+        o_y + al(H * W * cout * 4), cin * H * W * 4, cout * H * W * 4)
+    t += "import_nchw src=x:0:%d:%d:%d:%d dst=A:0:%d:%d:%d:%d\n" % (cin, cin, H, W, cin, cin, H, W)
+    t += "conv xr=0 yr=1 name=a in=A:0:%d:%d:%d:%d out=A:%d:%d:%d:%d:%d w=w1_weight act=1 cin=%d cout=%d mode=conv tile=0 k=1,1 s=1,1 p=0,0 d=1,1\n" % (
+        cin, cin, H, W, o_m, cmid, cmid, H, W, cin, cmid)
+    t += "conv xr=1 yr=2 name=b in=A:%d:%d:%d:%d:%d out=A:%d:%d:%d:%d:%d w=w2_weight act=0 cin=%d cout=%d mode=conv tile=%d k=1,1 s=1,1 p=0,0 d=1,1\n" % (
+        o_m, cmid, cmid, H, W, o_y, cout, cout, H, W, cmid, cout, tile2)
+    t += "export_nchw src=A:%d:%d:%d:%d:%d dst=y:0:%d:%d:%d:%d\n" % (o_y, cout, cout, H, W, cout, cout, H, W)
+    plan = m.add_plan("p", t)
+    plan.finalize()
+    return m, plan
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_the_producer_epilogue_raises_the_consumers_range(ctx, monkeypatch, graph):
+    """a -> b inside one plan (eager and as a captured graph): b's scale comes from the range a's epilogue noted (source 1, no pass over
+    the tensor), equals the scale of the tensor's true maximum, follows every run, and b is at full accuracy"""
     monkeypatch.setenv("ACCEL_SPLIT", "h2")
-    monkeypatch.setenv("ACCEL_RECAL_EVERY", "3")
-    cin, cout, H, W = 64, 64, 16, 16
-    w, x = rnd(5, cout, cin, 1, 1, scale=0.1), np.maximum(rnd(6, 1, cin, H, W), 0)
-    c = OneConv(ctx, cin, cout, H, W, 1, 76, w)
+    cin, cmid, cout, H, W = 64, 256, 128, 24, 40
+    w1, w2 = rnd(11, cmid, cin, 1, 1, scale=0.2), rnd(12, cout, cmid, 1, 1, scale=0.05)
+    x = rnd(13, 1, cin, H, W)
+    m, plan = _two_convs(ctx, cin, cmid, cout, H, W, w1, w2, 81, graph=graph)
     try:
-        c(x)                                   # run 0: probed
-        s0 = c.plan.ranges()["c"][0]
-        c(x * 2.0 ** -10); c(x * 2.0 ** -10)    # runs 1, 2: not probed
-        assert c.plan.ranges()["c"][0] == s0
-        c(x * 2.0 ** -10)                       # run 3: probed, the range moved by 2^-10
-        assert c.plan.ranges()["c"][0] == s0 * 2.0 ** 10
+        outs = {}
+        for f in (1.0, 1e-4, 300.0, 1.0):
+            m.write("x", np.float32(f) * x)
+            plan.run()
+            y = m.read("y", (1, cout, H, W))
+            mid = np.maximum(conv64(np.float32(f) * x, w1, 0), 0)
+            ref = conv64(mid.astype(np.float32), w2, 0)
+            s, src = plan.ranges()["b"]
+            assert src == 1 and plan.ranges()["a"][1] == 2             # b: from a's epilogue; a (reads an imported tensor): measured
+            assert 2.0 ** 13 <= s * float(mid.max()) * (1 + 1e-6) and s * float(mid.max()) * (1 - 1e-6) < 2.0 ** 14, (f, s, mid.max())
+            assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), f
+            outs.setdefault(f, y)
+            assert np.array_equal(y, outs[f])                           # f = 1.0 twice, with other frames between: bit-identical
     finally:
-        c.close()
+        m.close()
 
 
 def test_split_b3_plan_option_and_env(ctx, monkeypatch):
-    """ACCEL_SPLIT=b3 (or plan option split=b3) keeps the range-free bf16x3 form: no scale slots, mode 0"""
+    """ACCEL_SPLIT=b3 (or plan option split=b3) keeps the bf16x3 form: no range slots, mode 0"""
     monkeypatch.setenv("ACCEL_SPLIT", "b3")
     w = rnd(8, 64, 64, 1, 1, scale=0.1)
     c = OneConv(ctx, 64, 64, 16, 16, 1, 76, w)
@@ -193,26 +214,3 @@ def test_stem_fp16x2_is_as_accurate_as_bf16x3(ctx, monkeypatch):
             err[form] = float(np.abs(ctx.conv2d(x, w, None, 2, 3, 1, tile=51) - truth).max()) / sc
         print("stem vs float64 at pixel scale %g: bf16x3 %.2e, fp16x2 %.2e" % (xscale, err["b3"], err["h2"]))
         assert err["h2"] <= 3e-6 and err["h2"] <= 1.5 * err["b3"] + 1e-7, (xscale, err)
-
-
-def test_a_layer_left_without_a_range_is_probed_again(ctx, monkeypatch):
-    """an all-zero input says nothing about the range: the probed first run leaves the layer uncalibrated (scale 1), and the runs that
-    follow are probed as well until it has one -- it does not wait for the periodic re-calibration (here: never)"""
-    monkeypatch.setenv("ACCEL_SPLIT", "h2")
-    monkeypatch.setenv("ACCEL_RECAL_EVERY", "0")
-    cin, cout, H, W = 256, 128, 16, 32
-    w = rnd(3, cout, cin, 1, 1, scale=0.05)
-    x = np.maximum(rnd(4, 1, cin, H, W), 0) * np.float32(1e-4)          # small pixels: at scale 1 the lo terms would be sub-normal halves
-    c = OneConv(ctx, cin, cout, H, W, 1, 81, w)
-    try:
-        assert np.array_equal(c(np.zeros_like(x)), np.zeros((1, cout, H, W), np.float32))
-        assert c.plan.ranges()["c"] == (1.0, False)
-        ref = conv64(x, w, 0)
-        y = c(x)                                                            # probed again: the scale follows THIS frame
-        s, cal = c.plan.ranges()["c"]
-        assert cal and 2.0 ** 10 <= s * float(x.max()) < 2.0 ** 11
-        assert np.abs(y - ref).max() <= 1e-6 * np.abs(ref).max()
-        c(x)
-        assert c.plan.ranges()["c"] == (s, True)                            # and the runs after that are ordinary ones
-    finally:
-        c.close()

@@ -1,0 +1,98 @@
+"""A bound executor's forward is a pure function of its inputs and parameters (the reference: dff_deeplab/core/module.py:1011-1044,
+DataParallelExecutorGroup.py:330-354) -- also in the default fp16x2 arithmetic, whose pixel scales are derived inside every run
+from the largest |value| of each tensor in THAT run (csrc/range.h).  Round 4 calibrated those scales in probed runs and kept them:
+a frame's last bits depended on what the plan had seen before, and a range jump returned NaN frames until the next probe.
+
+  * foreign content against the ORACLE: predictors bound and first run on clip A, then -- without re-binding -- clip B at contrast
+    x0.1, x1 and x8, a black frame, and a x100 jump of the input range between two consecutive frames;
+  * the same frames after two different histories: bit-identical logits.
+"""
+import numpy as np
+import pytest
+
+from accel_amd import demo, mx
+from accel_amd.core import tester
+from accel_amd.utils import image, synth
+from oracle import graphs as G
+
+from parity_report import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pre(frames_bgr, cfg, f=1.0):
+    """preprocessed frames (1 x 3 x H x W fp32, lib/utils/image.py:224-235) at contrast f"""
+    return [(np.float32(f) * image.transform(im, cfg.network.PIXEL_MEANS)).astype(np.float32) for im in frames_bgr]
+
+
+def _run(runner, frames, interval):
+    """the demo schedule over preprocessed frames on an already bound runner (data_key = the previous frame, demo.py:176-181)"""
+    outs, prev = [], None
+    zero_feat = mx.nd.array(np.zeros((1, 2048, 1, 1), np.float32))
+    for idx, im in enumerate(frames):
+        cur = mx.nd.array(im)
+        if prev is None:
+            prev = cur
+        lg, lab = runner.step(idx, [cur, prev, zero_feat], interval)
+        outs.append((lg.asnumpy(), np.uint8(np.squeeze(lab.asnumpy()))))
+        prev = cur
+    return outs
+
+
+def test_foreign_content_after_binding_matches_the_oracle(demo_cfg):
+    H, W, interval = 512, 1024, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    P = dict(arg)
+    P.update(aux)
+    A = synth.make_clip(H, W, 2, seed=5001)
+    B = synth.make_clip(H, W, 2, seed=5002)
+    black = [np.zeros_like(B[0]), np.zeros_like(B[1])]
+    try:
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        _run(r, _pre(A, demo_cfg), interval)                       # binds both plans; every scale of that run came from clip A
+        for f in (0.1, 1.0, 8.0):
+            frames = _pre(B, demo_cfg, f)
+            outs = _run(r, frames, interval)
+            ref = G.run_clip(P, "18", frames, interval)
+            # flat 1e-3 where the logits are of the order the bar was written for; at contrast x8 they grow with the input and so does
+            # the fp32 rounding BOTH evaluations carry: 1e-5 of the largest logit there
+            check_against_oracle(outs, ref, "stateless: clip B at contrast x%g after clip A" % f, rel_tol=1e-5 if f > 1 else 0.0)
+        frames = _pre(black, demo_cfg)
+        outs = _run(r, frames, interval)
+        ref = G.run_clip(P, "18", frames, interval)
+        check_against_oracle(outs, ref, "stateless: black frames after contrast x8", min_classes=1)
+        # a x100 jump of the input range between two CONSECUTIVE frames: key frame of clip B, then its second frame 100x brighter
+        # (round 4: NaN frames until the next probed run, reported after the fact)
+        frames = [_pre(B, demo_cfg)[0], _pre(B, demo_cfg, 100.0)[1]]
+        outs = _run(r, frames, interval)
+        assert all(np.isfinite(lg).all() for lg, _ in outs)
+        ref = G.run_clip(P, "18", frames, interval)
+        check_against_oracle(outs, ref, "stateless: x100 range jump between consecutive frames", rel_tol=1e-5, min_classes=1)
+    finally:
+        tester.release_models()
+
+
+@pytest.mark.parametrize("version", ["18", "101"])
+def test_a_frame_does_not_depend_on_the_frames_before_it(demo_cfg, version):
+    """clip B after (i) nothing but the binding run on clip A, (ii) black frames, a x8 clip and a x0.01 clip: bit-identical logits"""
+    H, W, interval = 256, 512, 2
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params(version, H, W, demo_cfg)
+    A = synth.make_clip(H, W, 2, seed=5101)
+    B = _pre(synth.make_clip(H, W, 2, seed=5102), demo_cfg)
+    try:
+        r = demo.ClipRunner(version, demo_cfg, arg, aux, (H, W))
+        _run(r, _pre(A, demo_cfg), interval)
+        first = _run(r, B, interval)
+        _run(r, _pre([np.zeros_like(A[0])] * 2, demo_cfg), interval)
+        _run(r, _pre(A, demo_cfg, 8.0), interval)
+        _run(r, _pre(A, demo_cfg, 0.01), interval)
+        again = _run(r, B, interval)
+        for t, ((lg0, lab0), (lg1, lab1)) in enumerate(zip(first, again)):
+            assert np.isfinite(lg0).all()
+            assert np.array_equal(lg0, lg1), "frame %d of Accel-%s depends on the frames before it (max diff %g)" % (
+                t, version, float(np.abs(lg0 - lg1).max()))
+            assert np.array_equal(lab0, lab1)
+    finally:
+        tester.release_models()
