@@ -75,6 +75,11 @@ def _vote_all(ok, ctx, group):
     return int(t.item()) == 1
 
 
+def _vote_any(flag, ctx, group):
+    """collective OR of a per-rank flag over the group (every rank calls it)"""
+    return not _vote_all(not flag, ctx, group)
+
+
 def make_comm(ctx, group=None):
     """RCCL communicator of the C ABI (accel_comm_create) spanning the ranks of a torch.distributed group: the 128-byte
     unique id is made on the group's first rank and handed to the others through the process group (the rendezvous
@@ -154,11 +159,16 @@ class FrameGather(object):
         self.n = 0
         self.comm, self.transport_note = None, ""
         if self.on_cuda and transport in ("auto", "cabi"):
+            # The transport is decided by ALL ranks together.  make_comm succeeds or fails on every rank alike; what a rank does with a
+            # failure must be the same everywhere too: a root that contributes less than a full slot (or any rank asked for "cabi")
+            # cannot fall back, and then NOBODY may -- a peer that quietly went on to torch.distributed.gather would issue a collective
+            # the root never joins (round-4 advisor finding: hang or mismatched collectives with --root-relief).
+            must = _vote_any(transport == "cabi", ctx, group)
             try:
                 self.comm = make_comm(ctx, group)
-            except Exception as e:          # librccl not resolvable from the library: same protocol through torch
-                if transport == "cabi":
-                    raise
+            except Exception as e:          # librccl not resolvable from the library: same protocol through torch -- on every rank, or on none
+                if must:
+                    raise type(e)("%s (a rank of the group needs the C-ABI transport: no rank falls back)" % (e,))
                 self.transport_note = "C-ABI communicator unavailable (%s); torch.distributed transport" % (e,)
         self.transport = "cabi" if self.comm is not None else "torch"
         self.recv = [[torch.empty(shape, dtype=tdt, device=dev) for _ in range(self.world)] for _ in range(2)] \

@@ -487,6 +487,14 @@ class Lowering(object):
         # algorithmic HBM bytes of the launch: every operand once (input, weights, residual, outputs)
         kk = a["kernel"][0] * a["kernel"][1]
         in_elems = ho * wo * kk * _r4(cin) if op == "DeformableConvolution" else hi * wi * cin
+        if mode == "conv" and op == "Convolution":
+            # a kernel smaller than its stride never reads the pixels between its taps (the stride-2 1x1 layers res3a / res4a
+            # `branch1`, `branch2a`: a quarter of the input): only what is sampled counts as algorithmic traffic
+            sy, sx = a["stride"]
+            ky = (a["kernel"][0] - 1) * a["dilate"][0] + 1
+            kx = (a["kernel"][1] - 1) * a["dilate"][1] + 1
+            if ky < sy or kx < sx:
+                in_elems = min(in_elems, ho * min(ky, sy) * wo * min(kx, sx) * cin)
         w_elems = cout * cin * (16 if mode == "deconv2x" else kk)
         nbytes = 4.0 * (in_elems + ho * wo * cout * (1 + (res is not None) + (out2 is not None)))
         args["_elems"] = {"in": in_elems, "out": ho * wo * cout, "w": w_elems, "n": nb}

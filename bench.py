@@ -194,6 +194,7 @@ def roofline_from_launches(launches, dtype="f32"):
     dominant family; `hbm_class` is the same report for the HBM-regime launches; `all_conv.frac` = the share of the matrix-regime
     convolution time an ideal pipe would need."""
     fam, tot = {}, {"mfma": [0.0, 0.0, 0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0, 0.0, 0.0]}     # launches, ms, flops, bytes, ideal ms
+    cached = [0.0, 0.0, 0.0, []]      # launches, ms, bytes, names: algorithmic bytes / duration ABOVE the HBM peak -- served by the caches, never priced as HBM
     fl = ms = n = by = clip_ms = 0.0
     for op, d, wgt in launches:
         clip_ms += wgt * d
@@ -201,7 +202,16 @@ def roofline_from_launches(launches, dtype="f32"):
             continue
         fl += wgt * op["flops"]; by += wgt * op["bytes"]; ms += wgt * d; n += wgt
         name = conv_family(op, dtype)
-        regime = "hbm" if (op["bytes"] / (d * 1e-3) / 1e9 >= HBM_REGIME_GBPS or name not in PIPES) else "mfma"
+        gbps = op["bytes"] / (d * 1e-3) / 1e9
+        if gbps > HBM_PEAK_GBPS:
+            # no launch may be priced above what the part has: its operands came out of the Infinity Cache / L2 (small maps, weights of the
+            # previous launch), so it belongs to neither roof's class; reported separately, with names, so that a mis-counted `bytes`
+            # (round 4: the stride-2 1x1 layers counted the three quarters of the input they never read) shows up here instead of
+            # inflating hbm_class.achieved
+            cached[0] += wgt; cached[1] += wgt * d; cached[2] += wgt * op["bytes"]
+            cached[3].append("%s (%.0f GB/s)" % (op.get("name", "?"), gbps))
+            continue
+        regime = "hbm" if (gbps >= HBM_REGIME_GBPS or name not in PIPES) else "mfma"
         f = fam.setdefault(name, {"mfma": [0.0, 0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0, 0.0]})[regime]
         f[0] += wgt; f[1] += wgt * d; f[2] += wgt * op["flops"]; f[3] += wgt * op["bytes"]
         t = tot[regime]
@@ -247,6 +257,9 @@ def roofline_from_launches(launches, dtype="f32"):
                           "frac_of_achievable": round(hbm_gbps / HBM_ACHIEVABLE_GBPS, 4), "launches_per_step": int(hb[0]), "ms_per_step": round(hb[1], 3),
                           "what": "convolution launches whose algorithmic bytes (input + weights + residual + output, once each) / duration reach %.0f GB/s: "
                                   "priced as bytes/s against HBM (8 TB/s spec, %.1f TB/s achievable per MI355X_MICROARCH.md)" % (HBM_REGIME_GBPS, HBM_ACHIEVABLE_GBPS / 1e3)},
+            "cache_class": {"launches_per_step": int(cached[0]), "ms_per_step": round(cached[1], 3), "layers": cached[3][:12],
+                            "what": "convolution launches whose algorithmic bytes / duration EXCEED the %.0f GB/s HBM peak: operands served by the caches; "
+                                    "excluded from hbm_class and from the families' rates" % HBM_PEAK_GBPS},
             "all_conv": {"frac": round(mf[4] / mf[1], 4) if mf[1] else None,
                          "what": "time-weighted over every MATRIX-regime convolution launch of a step: sum(executed flop_i / peak_i) / sum(t_i)",
                          "matrix_regime_ms_per_step": round(mf[1], 3), "hbm_regime_ms_per_step": round(hb[1], 3),
@@ -376,15 +389,37 @@ def _pmc_traffic(version, H, W, interval, dtype, B):
     import glob
     files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_traffic.json")))
     if not files or not (version == "18" and (H, W) == (1024, 2048) and interval == 5 and dtype == "f32"):
-        return None, None
+        return None, None, []
     with open(files[-1]) as f:
         tr = json.load(f)
     if int(tr.get("batch", 1)) != B:
-        return None, None
+        return None, None, []
     d = tr.get("dominant", tr)
     return (round(d["read_bytes_per_launch"] + d["write_bytes_per_launch"]),
             "HBM read + write bytes per launch of %s from the committed PMC passes (%s): %s"
-            % (" / ".join(d.get("kernels", ["the convolution kernels"])), os.path.relpath(files[-1], HERE), tr["method"]))
+            % (" / ".join(d.get("kernels", ["the convolution kernels"])), os.path.relpath(files[-1], HERE), tr["method"]),
+            d.get("kernels", []))
+
+
+# rocprof kernel name -> the families of roofline_from_launches its launches fall into
+PMC_KERNEL_FAMILIES = {"conv_b3r_kernel": ("conv_h2_kernel", "conv_igemm_b3_kernel", "conv_f16_kernel"), "conv_igemm_b3_kernel": ("conv_igemm_b3_kernel",),
+                       "conv_wino_b3_kernel": ("conv_wino_h2_kernel", "conv_wino_b3_kernel"), "conv_wino_b3s_kernel": ("conv_wino_h2_kernel", "conv_wino_b3_kernel")}
+
+
+def pair_traffic(roof, traffic, note, kernels):
+    """roofline.traffic belongs to a SET of launches (every launch of the kernels the PMC passes sampled): it is paired with the
+    algorithmic bytes of the same set -- all regimes of the families those kernels carry -- and the ratio is printed."""
+    roof["traffic"], roof["traffic_note"] = traffic, note
+    if traffic is None:
+        return roof
+    fams = sorted(set(f for k in kernels for f in PMC_KERNEL_FAMILIES.get(k, ()) if f in roof["families"]))
+    n = sum(roof["families"][f]["launches_per_step"] for f in fams)
+    by = sum(roof["families"][f].get("algorithmic_bytes_per_launch", 0) * roof["families"][f]["launches_per_step"] for f in fams)
+    if n:
+        roof["traffic_algorithmic_bytes_per_launch"] = round(by / n)
+        roof["traffic_ratio"] = round(traffic / (by / n), 3)
+        roof["traffic_set"] = "all %d launches per step of the families %s (matrix and HBM regime alike) -- NOT the deep-K class `achieved` is quoted on" % (n, ", ".join(fams))
+    return roof
 
 
 def _gather_self_secondary(wl, a, B, H, W, local_rank, steps, warm, rate):
@@ -558,9 +593,10 @@ def _run(a):
                                 "(same timing definition, other hardware), null when that secondary was not measured",
                "dtype": (("f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
                           "and, for most layers, 'fp16x2': each fp32 operand as TWO half terms hi + lo (22-23 significant bits, operands "
-                          "centred in the half range by exact powers of two: weights per channel, pixels by a probed per-layer scale), "
+                          "centred in the half range by exact powers of two: weights per channel, pixels by a scale each convolution derives from the largest "
+                          "|value| of its input tensor IN THE SAME RUN -- no calibration, a run is a pure function of its inputs), "
                           "three fp16 MFMA products hi*hi + hi*lo + lo*hi accumulated in fp32 -- error against float64 equal to the "
-                          "bf16x3 form's and below an fp32 accumulation's, tests/test_h2_gpu.py; secondary.*_bf16x3_split = the range-free "
+                          "bf16x3 form's and below an fp32 accumulation's, tests/test_h2_gpu.py, tests/test_stateless_gpu.py; secondary.*_bf16x3_split = the "
                           "three-term bf16 form (six products), secondary.*_fp32_mfma_only = neither)"
                           if os.environ.get("ACCEL_SPLIT", "h2") == "h2" else
                           "f32 (storage, accumulation and results; the launch geometries the tuner picks include the fp32 MFMA, Winograd F(2x2,3x3) "
@@ -591,8 +627,7 @@ def _run(a):
     if rank == 0 and rank_ms is not None:
         out["rank_ms_per_step"] = rank_ms
     if rank == 0 and not a.no_roofline:
-        out["roofline"] = wl.conv_roofline(a.dtype)
-        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = _pmc_traffic(a.version, H, W, a.interval, a.dtype, B)
+        out["roofline"] = pair_traffic(wl.conv_roofline(a.dtype), *_pmc_traffic(a.version, H, W, a.interval, a.dtype, B))
 
     # ---- secondary measurements, same harness (single GPU, headline configuration only) ----------------------------------
     if rank == 0 and world == 1 and dist is None and a.secondary == "auto" and headline_cfg:
@@ -669,7 +704,7 @@ def _run(a):
                 sec["accel18_batch%d_bf16x3_split" % B] = {
                     "value": rate(w4, el, steps2), "unit": "frames/s", "clips_per_call": B,
                     "what": "the headline workload with ACCEL_SPLIT=b3: every matrix-core geometry in its bf16x3 form (three exact bf16 "
-                            "terms per operand, six products, no range calibration) instead of fp16x2",
+                            "terms per operand, six products, no range slots) instead of fp16x2",
                     "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_peak": rf["all_conv"]["frac"]}
                 w4.close()
             except Exception as e:

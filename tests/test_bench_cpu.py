@@ -74,3 +74,29 @@ def test_roofline_is_split_by_regime():
     f = r["families"]["conv_igemm_b3_kernel"]
     assert f["matrix_regime"]["launches_per_step"] == 4 and f["hbm_regime"]["launches_per_step"] == 2
     assert r["all_conv"]["frac"] == pytest.approx(0.48)        # the HBM-regime launches no longer dilute the matrix fraction
+
+
+def test_no_launch_is_priced_above_the_hbm_peak():
+    """round 4 priced res3a_branch2a at 11.4 TB/s "algorithmic" (its byte count included the three quarters of the input a stride-2
+    1x1 never reads) and let it inflate hbm_class.achieved: a launch above the 8 TB/s the part has is served by the caches and is
+    reported in a class of its own, by name"""
+    short = (op(76, flops=1e10, nbytes=2e9), 0.5, 2)           # 4 TB/s: HBM regime
+    hot = (dict(op(76, flops=1e9, nbytes=1e9), name="res3a_branch2a"), 0.1, 1)      # 10 TB/s: cannot come from HBM
+    r = bench.roofline_from_launches([short, hot, (op(76), 1.0, 1)], "f32")
+    assert r["hbm_class"]["launches_per_step"] == 2 and r["hbm_class"]["achieved"] == pytest.approx(4000.0)
+    assert r["cache_class"]["launches_per_step"] == 1 and r["cache_class"]["layers"] == ["res3a_branch2a (10000 GB/s)"]
+    assert all(f["launches_per_step"] <= 3 for f in r["families"].values())
+    assert r["hbm_class"]["achieved"] <= bench.HBM_PEAK_GBPS
+
+
+def test_traffic_is_paired_with_the_algorithmic_bytes_of_the_same_launch_set():
+    """roofline.traffic (PMC bytes per launch of every conv_b3r / conv_igemm_b3 launch) against the algorithmic bytes of THAT set --
+    round 4's line put it beside the deep-K class's bytes, which read as 2.29x instead of 1.45x"""
+    deep = (op(76, mode=3, flops=2e11, nbytes=3e8), 1.0, 1)       # matrix regime
+    short = (op(77, mode=3, flops=1e10, nbytes=6e8), 0.15, 2)     # HBM regime, same rocprof kernel name
+    wino = (op(43, mode=3, flops=1e11, nbytes=4e8), 0.5, 1)       # another kernel: not in the sampled set
+    r = bench.roofline_from_launches([deep, short, wino], "f32")
+    r = bench.pair_traffic(r, 750000000, "note", ["conv_igemm_b3_kernel", "conv_b3r_kernel"])
+    assert r["traffic_algorithmic_bytes_per_launch"] == 500000000 and r["traffic_ratio"] == pytest.approx(1.5)
+    assert r["algorithmic_bytes_per_launch"] == 300000000      # the deep-K class `achieved` is quoted on: a different set
+    assert bench.pair_traffic(dict(r), None, None, [])["traffic"] is None

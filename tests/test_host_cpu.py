@@ -705,3 +705,17 @@ def test_half_storage_set_of_the_f16_mode(demo_cfg, version):
     for kw in (dict(conv_dtype="f16", store_f16=False), dict(conv_dtype="f32", store_f16=True)):
         text, lw = _plan(version, False, H=256, W=512, **kw)
         assert ":h " not in text and not lw.half_bufs
+
+
+def test_algorithmic_bytes_of_a_strided_1x1_count_only_the_sampled_pixels():
+    """lower.py lower_anchor: res3a / res4a `branch1` and `branch2a` are 1x1 / stride 2 -- they read one pixel in four
+    (resnet_v1_101_flownet_deeplab.py:646-660).  Round 4 counted the whole input and priced those launches above the HBM peak."""
+    text, _ = _plan("18", True, 256, 512)
+    kv = lambda l: dict(t.split("=", 1) for t in l.split()[1:] if "=" in t)
+    ops = {kv(l)["name"]: kv(l) for l in text.split("\n") if l.startswith("conv ")}
+    for name, cin, cout, ho, wo in (("res3a_branch2a", 256, 128, 32, 64), ("res3a_branch1", 256, 512, 32, 64), ("res4a_branch2a", 512, 256, 16, 32)):
+        want = 4.0 * (ho * wo * cin + ho * wo * cout) + 4.0 * cin * cout
+        assert float(ops[name]["bytes"]) == pytest.approx(want, rel=1e-5), name
+    # a 3x3 / stride 2 layer reads everything
+    b = ops["res3a_branch2b"] if ops["res3a_branch2b"]["s"] != "1,1" else ops["conv4"] if "conv4" in ops else None
+    assert b is None or float(b["bytes"]) > 0
