@@ -96,6 +96,13 @@ struct accel_model {
     // which buffer holds the current propagated feature: 0 = `feat`, 1 = `feat_b` (non-key graphs may be bound as a pair of
     // plans `cur` / `cur_b` that ping-pong between the two instead of copying the warped feature back; whoever wrote last)
     int feat_slot = 0;
+    // Score-resolution fusion (score_fuse_lowres_kernel: both upsampling filters the same for every class): the fused map lives in the
+    // persistent buffer `scores` ([images][H/16][W/16][ncls rounded up to 4] fp32) and `score_tpl` is the launch that expands such a map
+    // into logits + labels -- the plans' own last step, and what accel_expand_scores / accel_gather_scores run on a map that came from
+    // another GPU: the full-size logits are a pure function of a map 256x smaller.
+    ScoreTailParams score_tpl;
+    bool has_score_tpl = false;
+    int score_images = 0, score_zcs = 0;
     void source_written(const std::string& src) {
         ++generation[src];
         if (src == "feat") feat_slot = 0;
@@ -144,6 +151,7 @@ struct Op {
     // epilogues of earlier ops of this plan -- its view is measured by a launch of its own right before it (assign_range_slots)
     int rs_in = -1, rs_out = -1, rs_out2 = -1;
     bool measure = false;
+    bool fold = false;          // this op is the first reader of its input slot after a write: the slot's partial words are folded into word 0 first
     unsigned* yr = nullptr;     // resolved slots of the outputs (null: nobody needs them); convolutions, pools and the deformable sampler
     unsigned* y2r = nullptr;    // carry them in their parameter blocks as well
 };
@@ -987,14 +995,25 @@ static int finalize_op(accel_plan* p, Op& op)
                           !memcmp(hl->data.data(), hr->data.data() + (size_t)c * 1024, 4096);
             if (uniform) {
                 const int zCs = roundup(q.ncls, 4);
-                void* z = nullptr;
-                std::vector<float> zeros((size_t)op.a.N * q.Hs * q.Ws * zCs, 0.f);
-                if ((rc = dev_upload(p, zeros.data(), zeros.size() * sizeof(float), &z))) return rc;
-                op.tail_z = static_cast<float*>(z);
+                // the fused map is the model's persistent buffer `scores` (shared by the key and the non-key plan, like `logits`)
+                const size_t zbytes = (size_t)op.a.N * q.Hs * q.Ws * zCs * sizeof(float);
+                DevBuf& zb = p->m->pbufs["scores"];
+                if (!zb.ptr) {
+                    HIP_TRY(hipMalloc(&zb.ptr, zbytes));
+                    zb.bytes = zbytes;
+                    HIP_TRY(hipMemsetAsync(zb.ptr, 0, zbytes, p->m->ctx->stream));      // the pad channel stays zero
+                } else if (zb.bytes != zbytes) {
+                    return fail(ACCEL_ERR_PLAN, "score_tail %s: the model's `scores` buffer has %zu bytes, this plan needs %zu", op.name.c_str(), zb.bytes, zbytes);
+                }
+                op.tail_z = static_cast<float*>(zb.ptr);
                 op.tail_lowres = q;
                 op.tail_lowres.left = op.tail_z; op.tail_lowres.lCs = zCs;
                 op.tail_lowres.right = nullptr; op.tail_lowres.wr = nullptr; op.tail_lowres.cw = nullptr;   // cb stays: bias after upsampling
                 op.tail_lowres.uniform_w = 1;
+                p->m->score_tpl = op.tail_lowres;
+                p->m->has_score_tpl = true;
+                p->m->score_images = op.a.N;
+                p->m->score_zcs = zCs;
             }
         }
         return 0;
@@ -1069,10 +1088,12 @@ static int launch_op(accel_plan* p, Op& op)
 // Issues the plan: the range slots are zeroed, then every op in list order on the context's compute stream (under stream capture this
 // becomes a linear graph).  An fp16x2-form convolution whose input tensor no earlier op of the plan measured (Op::measure) is preceded
 // by the pass that does (misc.hip range_amax_kernel).
-static int launch_measure(accel_plan* p, Op& op)
+static int launch_measure(accel_plan* p, Op& op)      // what goes in front of an fp16x2-form convolution: the measuring pass (if any), the fold (if any)
 {
     const ConvParams& c = op.conv;
-    hipError_t e = launch_range_amax(c.x, (long)op.a.N * c.H * c.W, c.Cin, c.xCs, const_cast<unsigned*>(c.xr_slot), p->m->ctx->stream);
+    hipError_t e = hipSuccess;
+    if (op.measure) e = launch_range_amax(c.x, (long)op.a.N * c.H * c.W, c.Cin, c.xCs, const_cast<unsigned*>(c.xr_slot), p->m->ctx->stream);
+    if (e == hipSuccess && (op.measure || op.fold)) e = launch_range_fold(const_cast<unsigned*>(c.xr_slot), p->range_flag_dev, (int)(&op - p->ops.data()), p->m->ctx->stream);
     if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "range pass of conv %s failed: %s", op.name.c_str(), hipGetErrorString(e));
     return 0;
 }
@@ -1083,9 +1104,27 @@ static int run_eager(accel_plan* p)
         return fail(ACCEL_ERR_HIP, "clearing the range slots of plan '%s' failed", p->role.c_str());
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
-        int rc = op.measure ? launch_measure(p, op) : 0;
+        int rc = (op.measure || op.fold) ? launch_measure(p, op) : 0;
         if (!rc) rc = launch_op(p, op);
         if (rc) return rc;
+        // ACCEL_CHECK_FINITE=1 (diagnostics, eager runs only -- set ACCEL_HIP_GRAPH=0): the first op of a run whose fp32 output holds a
+        // non-finite value is named on stderr
+        static const char* chk = getenv("ACCEL_CHECK_FINITE");
+        if (chk && chk[0] == '1' && !p->gexec && (op.kind == OP_CONV || op.kind == OP_POOL || op.kind == OP_PREP_RGB) && p->n_slots) {
+            const BufRef& o = op.kind == OP_PREP_RGB ? op.b : op.b;
+            if (o.esize == 4 && o.ptr) {
+                static unsigned* scratch = nullptr;
+                if (!scratch) hipMalloc((void**)&scratch, RANGE_WORDS * sizeof(unsigned));
+                hipStream_t st = p->m->ctx->stream;
+                launch_range_clear(scratch, 1, st);
+                launch_range_amax(o.ptr, (long)o.N * o.H * o.W, roundup(o.C, 4), o.Cs, scratch, st);
+                launch_range_fold(scratch, nullptr, 0, st);
+                unsigned bits = 0;
+                hipStreamSynchronize(st);
+                hipMemcpy(&bits, scratch, 4, hipMemcpyDeviceToHost);
+                if (bits >= 0x7F800000u) fprintf(stderr, "[accel check] plan %s op %zu %s %s: output holds a non-finite value (largest |x| bits 0x%08x)\n", p->role.c_str(), i, op.kind_name.c_str(), op.name.c_str(), bits);
+            }
+        }
     }
     return 0;
 }
@@ -1137,20 +1176,22 @@ static int assign_range_slots(accel_plan* p)
         return it == slot_of.end() ? nullptr : p->range + (size_t)it->second * RANGE_WORDS;
     };
     std::vector<int> state(n, 0);      // 0: no writer yet, 1: every writer so far had the epilogue, 2: some writer had not
+    std::vector<char> dirty(n, 0);     // partial words written since the last fold
     auto wrote = [&](int id, bool has_epilogue) {
         auto it = id < 0 ? slot_of.end() : slot_of.find(id);
         if (it == slot_of.end()) return;
         int& st = state[it->second];
         st = (has_epilogue && st != 2) ? 1 : 2;
+        dirty[it->second] = 1;
     };
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
         if (in_slot[i] >= 0) {      // reader first: an op never feeds itself
             ConvParams& c = op.conv;
             c.xr_slot = p->range + (size_t)in_slot[i] * RANGE_WORDS;
-            c.rflag = p->range_flag_dev;
-            c.op_index = (int)i;
             op.measure = state[in_slot[i]] != 1;
+            op.fold = op.measure || dirty[in_slot[i]];      // (a measuring pass raises partial words as well)
+            dirty[in_slot[i]] = 0;
         }
         switch (op.kind) {
         case OP_CONV:
@@ -1428,7 +1469,11 @@ static int autotune_plan(accel_plan* p)
             float best = 1e30f; TuneVal bv = {c.force_tile, 0, 0};
             if (c.xr_slot) {      // the fp16x2 candidates read the range of the input as it lies there now
                 HIP_TRY(launch_range_clear(const_cast<unsigned*>(c.xr_slot), 1, st));
-                if ((rc = launch_measure(p, op))) break;
+                const bool m0 = op.measure;
+                op.measure = true;
+                rc = launch_measure(p, op);
+                op.measure = m0;
+                if (rc) break;
             }
             for (const Cand& k : cands[i]) {
                 ConvParams q = c;
@@ -1655,6 +1700,10 @@ extern "C" int accel_plan_finalize(accel_plan* p)
     }
     int rrc = snap.restore();
     if (rrc) return rrc;
+    // the tuning launches and the warm-up run worked on whatever the buffers held (tuning: an op's candidates on the output of ONE
+    // launch of its predecessor): a non-finite range seen there says nothing about a frame
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    if (p->range_flag) p->range_flag[0] = p->range_flag[1] = 0u;
     p->finalized = true;
     return 0;
 }
@@ -1727,13 +1776,22 @@ extern "C" int accel_plan_op_range(accel_plan* p, int i, float* scale, int* meas
     if (scale) *scale = 0.f;
     if (measured) *measured = 0;
     if (op.kind != OP_CONV || !op.conv.xr_slot) return 0;
-    std::vector<unsigned> w(RANGE_WORDS);
-    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
-    HIP_TRY(hipMemcpy(w.data(), op.conv.xr_slot, RANGE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost));
     unsigned bits = 0u;
-    for (int k = 0; k < RANGE_SUB; ++k) bits = std::max(bits, w[(size_t)k * RANGE_STRIDE]);
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    HIP_TRY(hipMemcpy(&bits, op.conv.xr_slot, sizeof bits, hipMemcpyDeviceToHost));      // word 0: what the convolution read
     if (scale) *scale = range_scale(bits).s;
     if (measured) *measured = bits ? (op.measure ? 2 : 1) : 0;
+    return 0;
+}
+
+// diagnostics: the RANGE_WORDS words of conv op i's input slot (word 0 = what the convolution read, words RANGE_PART_OFF.. = the partial words)
+extern "C" int accel_plan_op_range_words(accel_plan* p, int i, unsigned* words, int n_words)
+{
+    if (!p || !p->finalized || i < 0 || i >= (int)p->ops.size() || !words || n_words < RANGE_WORDS) return fail(ACCEL_ERR_ARG, "accel_plan_op_range_words: bad argument");
+    const Op& op = p->ops[i];
+    if (op.kind != OP_CONV || !op.conv.xr_slot) return fail(ACCEL_ERR_ARG, "accel_plan_op_range_words: op %d has no range slot", i);
+    HIP_TRY(hipStreamSynchronize(p->m->ctx->stream));
+    HIP_TRY(hipMemcpy(words, op.conv.xr_slot, RANGE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1750,7 +1808,7 @@ extern "C" int accel_plan_profile(accel_plan* p, int iters, float* ms, int n_ms)
         if (p->n_slots) HIP_TRY(launch_range_clear(p->range, p->n_slots, st));
         for (size_t i = 0; i < n && !rc; ++i) {
             HIP_TRY(hipEventRecord(ev[2 * i], st));
-            if (p->ops[i].measure) rc = launch_measure(p, p->ops[i]);      // the range pass belongs to the op that needs it
+            if (p->ops[i].measure || p->ops[i].fold) rc = launch_measure(p, p->ops[i]);      // the range pass / fold belongs to the op that needs it
             if (!rc) rc = launch_op(p, p->ops[i]);
             HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
         }
@@ -2446,5 +2504,51 @@ extern "C" int accel_gather_frames(accel_comm* c, const void* sendbuf, size_t se
     HIP_TRY(hipEventRecord(c->sent[s], c->stream));
     c->used[s] = true;
     ++c->n;
+    return 0;
+}
+
+// ---- the gather at SCORE resolution ------------------------------------------------------------------------------------------------
+// With uniform upsampling filters the fp32 logits of a frame (19 x H x W: 159 MB at 1024x2048) are a pure function of the fused score
+// map the plan leaves in `scores` (20 x H/16 x W/16 floats: 0.66 MB).  Peers send that map; the root expands every block with the very
+// launch its own plans end with (score_tail_uniform_kernel over the model's filter and bias), so the expanded logits are bit-identical
+// to what the peer computed.  Round 4 measured the logits gather at 93 GB/s per peer link against ~77 sustainable: link-bound.
+extern "C" int accel_expand_scores(accel_model* m, const void* scores_dev, int n_images, float* logits_dev, unsigned char* labels_dev, accel_comm* on_comm_stream_of)
+{
+    if (!m || !scores_dev || !logits_dev || !labels_dev || n_images < 1) return fail(ACCEL_ERR_ARG, "accel_expand_scores: bad argument");
+    if (!m->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_expand_scores: the model fuses its scores at full resolution (no `scores` buffer: the upsampling "
+                                                       "filters are not uniform, or no plan with a two-head score tail is finalized)");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    ScoreTailParams q = m->score_tpl;
+    q.left = static_cast<const float*>(scores_dev);
+    q.logits = logits_dev;
+    q.labels = labels_dev;
+    q.N = n_images;
+    const hipError_t e = launch_score_tail(q, on_comm_stream_of ? on_comm_stream_of->stream : m->ctx->stream);
+    if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "accel_expand_scores: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Every rank contributes the `scores` buffer of `m` (own_images of the slot_images a slot holds: only the root may contribute fewer);
+// the root receives the maps into recv_scores ([nranks][slot_images] maps) and expands rank r's block into logits_out / labels_out at
+// image offset r * slot_images, on the communication stream right behind the receives -- no host synchronisation anywhere; the results
+// are valid after accel_comm_sync.  Peers pass NULL for the three root-side buffers.
+extern "C" int accel_gather_scores(accel_comm* c, accel_model* m, int own_images, int slot_images, void* recv_scores, float* logits_out,
+                                   unsigned char* labels_out, int root)
+{
+    if (!c || !m || own_images < 1 || slot_images < own_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: bad argument");
+    if (!m->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_gather_scores: the model has no `scores` buffer (see accel_expand_scores)");
+    if (own_images > m->score_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: %d images asked for, the model's plans produce %d", own_images, m->score_images);
+    if (c->rank == root && (!recv_scores || !logits_out || !labels_out)) return fail(ACCEL_ERR_ARG, "accel_gather_scores: the root needs its three buffers");
+    const ScoreTailParams& t = m->score_tpl;
+    const size_t map_bytes = (size_t)t.Hs * t.Ws * m->score_zcs * sizeof(float);
+    int rc = accel_gather_frames(c, m->pbufs["scores"].ptr, (size_t)own_images * map_bytes, recv_scores, (size_t)slot_images * map_bytes, root);
+    if (rc || c->rank != root) return rc;
+    const size_t img_logits = (size_t)t.ncls * t.H * t.W, img_labels = (size_t)t.H * t.W;
+    for (int r = 0; r < c->nranks; ++r) {
+        const int n = r == root ? own_images : slot_images;
+        rc = accel_expand_scores(m, static_cast<const char*>(recv_scores) + (size_t)r * slot_images * map_bytes, n,
+                                 logits_out + (size_t)r * slot_images * img_logits, labels_out + (size_t)r * slot_images * img_labels, c);
+        if (rc) return rc;
+    }
     return 0;
 }

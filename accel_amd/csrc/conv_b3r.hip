@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
     const int HoWo = p.Ho * p.Wo;
     // fp16x2 form: the power of two that centres the pixels in the half range, from the range slot of the input tensor (range.h)
     RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
-    if constexpr (NPL == 2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    if constexpr (NPL == 2) rs = range_prologue(p.xr);
     const float xs = rs.s;
 
     // ---- pixel-tile staging (same row order as conv_igemm_b3_kernel: rows of a group of 8 as 0,4,1,5,2,6,3,7) ------------

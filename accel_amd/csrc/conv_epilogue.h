@@ -89,8 +89,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][j][e];
     }
+    // ---- range slots of the outputs (range.h) ----
+    // A pass of its own over the accumulators, BEHIND the store loop and with nothing of it kept live: the values are recomputed from
+    // acc (3-5 vector instructions each).  Woven into the store loop the same bookkeeping cost 30-40 registers per lane -- the
+    // 128x128 tile went from 94 to 128 registers with scratch spills and lost a resident block, the 128x64 tile two (round 5, first
+    // version: headline 626 -> 571 frames/s).  Rows past M do not count (masked where the tile is ragged), channels past Cout_store
+    // neither; rows a cropped deconvolution drops (odd sizes) do: they are outputs of the same layer, the slot stays a bound and a
+    // function of the run's data.
+#ifdef RANGE_AB_NO_NOTE
+    const bool note = false, note2 = false;
+#else
     const bool note = p.yr != nullptr, note2 = p.y2 && p.y2r != nullptr;
+#endif
     unsigned rmax = 0u, rmax2 = 0u;
+    // per value: one fused multiply-add (none behind a residual: the accumulators already hold the pre-activation value) and one
+    // floating-point maximum -- |v| is v after a ReLU (a running maximum that starts at 0 IS the ReLU), max(v, -slope v) after a leaky
+    // one, the absolute-value source modifier otherwise.  (A NaN drops out of a floating-point maximum: it reaches the outputs
+    // through the matrix instructions as in fp32 arithmetic; an infinity stays visible and is reported by the fold.)
+    auto note_block = [&](int j) {
+        const bool ragged = rbase - 4 * (lane >> 5) + MI * 32 > p.M;      // wave-uniform: some rows of this wavefront lie past M
+        float mj = 0.f, mj2 = 0.f;
+        const float nslope = -p.slope;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = p.res ? acc[i][j][e] : acc[i][j][e] * sc[j] + sf[j];
+                if (ragged && rbase + i * 32 + (e & 3) + 8 * (e >> 2) >= p.M) v = 0.f;
+                if (p.act == 1) mj = fmaxf(mj, v);
+                else if (p.act == 2) mj = fmaxf(fmaxf(mj, v), v * nslope);
+                else mj = fmaxf(mj, __builtin_fabsf(v));
+                if (note2) {
+                    const float r = p.act == 1 ? fmaxf(v, 0.f) : p.act == 2 ? (v > 0.f ? v : v * p.slope) : v;
+                    mj2 = fmaxf(mj2, r * sc2[j] + sf2[j]);      // y2 = relu(.): the running maximum starts at 0
+                }
+            }
+        if (cok[j]) {
+            const unsigned b = __builtin_bit_cast(unsigned, mj), b2 = __builtin_bit_cast(unsigned, mj2);
+            rmax = b > rmax ? b : rmax; rmax2 = b2 > rmax2 ? b2 : rmax2;
+        }
+    };
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         if constexpr (RES_PER_J) {
@@ -108,8 +146,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][e];
             }
+            if (note || note2) note_block(j);
         }
-        unsigned mj = 0u, mj2 = 0u;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -127,21 +165,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     if (p.act == 1) v[e] = fmaxf(v[e], 0.f);
                     else if (p.act == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
                     buf_store1(yr, pix[e] != OOB ? (pix[e] * p.yCs + co[j]) * 4u : OOB, v[e]);
-                    if (note) { const unsigned b = pix[e] != OOB ? range_abs_bits(v[e]) : 0u; mj = b > mj ? b : mj; }
                 }
                 if (p.y2) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u = fmaxf(v[e] * sc2[j] + sf2[j], 0.f);
-                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, u);
-                        if (note2) { const unsigned b = pix[e] != OOB ? range_abs_bits(u) : 0u; mj2 = b > mj2 ? b : mj2; }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        buf_store1(y2r, pix[e] != OOB ? (pix[e] * p.y2Cs + co[j]) * 4u : OOB, fmaxf(v[e] * sc2[j] + sf2[j], 0.f));
                 }
             }
         }
-        rmax = mj > rmax ? mj : rmax; rmax2 = mj2 > rmax2 ? mj2 : rmax2;
     }
-    const unsigned key = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 7u * blockIdx.y;
+    // (behind the stores: the pass runs while they drain; the accumulators are still there, the values are recomputed from them)
+    if constexpr (!RES_PER_J) {
+        if (note || note2) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) note_block(j);
+        }
+    }
+    // one atomic per wavefront into the partial word its index picks (1024 of them: no two wavefronts in flight meet)
+    const unsigned key = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (note) range_note_wave(p.yr, rmax, key);
     if (note2) range_note_wave(p.y2r, rmax2, key);
 }

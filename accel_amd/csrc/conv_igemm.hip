@@ -949,7 +949,7 @@ __global__ void splitk_reduce_kernel(ConvParams p, int classes)
     const int N4 = p.Cout_store / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     // fp16x2 form: the partial sums carry the pixel scale of the launch that wrote them -- the same slot, the same value (range.h)
-    const float xinv = range_prologue(p.xr, nullptr, 0).inv;
+    const float xinv = range_prologue(p.xr).inv;
     unsigned rmax = 0u, rmax2 = 0u;
     if (idx < (long)classes * p.M * N4) {
     const int c4 = (int)(idx % N4);

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv_stem_b3_kernel(ConvParams p, int 
     constexpr int TSY = OTH, TSX = OTW;      // conv rows / columns between the origins of neighbouring tiles
     // fp16x2 form: the pixel scale from the range slot of the image tensor (range.h)
     RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
-    if constexpr (H2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    if constexpr (H2) rs = range_prologue(p.xr);
     const float xs = rs.s, xinv = rs.inv;
     unsigned rmax = 0u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void conv_wino_b3_kernel(ConvParams p)
     // fp16x2 form: the pixel scale from the range slot of the input tensor (range.h); the transformed patch B^T d B is up to 4x the
     // largest pixel, so V is split at a quarter of it (the factor 4 is in scale_h2w, host)
     RangeScale rs; rs.s = 1.f; rs.inv = 1.f;
-    if constexpr (H2) rs = range_prologue(p.xr, p.rflag, p.op_index);
+    if constexpr (H2) rs = range_prologue(p.xr);
     const float xs = H2 ? rs.s * 0.25f : 1.f, xinv = rs.inv;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 

@@ -74,17 +74,16 @@ struct ConvParams {
     const float* scale_h2s; // scale[] with the stem weights' exponents folded in
     const void* wubh;      // conv_wino_b3.hip / conv_wino_b3s.hip: U as two half planes in the layout of wub; null: not offered
     const float* scale_h2w; // scale[] with U's exponents (and the factor 4 of the quarter-scale V split) folded in
-    // Range slots (range.h): a slot is RANGE_SUB sub-slots of one word, RANGE_STRIDE words apart, zero at the start of every run of
-    // the plan; every kernel that writes a tensor some fp16x2-form convolution reads raises the slot to the largest |value| it
-    // stored (bit pattern of the absolute value, atomicMax: order-independent, so the result is deterministic), the reader takes the
-    // maximum over the sub-slots.  A reader whose input has a writer without that epilogue (or none inside the plan: a persistent
-    // buffer written by another plan or by the host) is preceded by a measuring launch (misc.hip range_amax_kernel) of its view.
+    // Range slots (range.h): a slot is one word the reader takes and RANGE_PART partial words, zero at the start of every run of the
+    // plan; every kernel that writes a tensor some fp16x2-form convolution reads raises a partial word to the largest |value| it
+    // stored (bit pattern of the absolute value, atomicMax: order-independent, so the result is deterministic); a one-block fold
+    // kernel in front of the first reader takes their maximum into word 0.  A reader whose input has a writer without that epilogue
+    // (or none inside the plan: a persistent buffer written by another plan or by the host) is preceded by a measuring launch
+    // (misc.hip range_amax_kernel) of its view.
     const unsigned* xr;      // input range slot; set by the dispatcher for the fp16x2 launch alone (every other kernel of the layer sees null)
     const unsigned* xr_slot; // the layer's input range slot; null: the layer has no fp16x2 form
     unsigned* yr;            // range slot of the tensor `y` is (part of); null: no fp16x2-form convolution reads it
     unsigned* y2r;           // the same for y2
-    unsigned* rflag;         // host-mapped word: an fp16x2-form convolution that finds a non-finite range writes op_index + 1 (ACCEL_ERR_RANGE)
-    int op_index;
     // half activation storage (f16-mode plans; conv_b3d.hip NPL = 1 only): the view is stored as half (2 bytes per element, channel
     // strides in elements, x_bytes / y_bytes / res_bytes in bytes); values are rounded (RTNE) when stored, after the whole epilogue
     int x_half, y_half, res_half;
@@ -201,7 +200,8 @@ hipError_t launch_copy_view(const float* src, int sCs, float* dst, int dCs, int 
 // fp16x2 form: max |x| of a view (pixels x C channels, channel stride Cs) raised into a range slot -- in front of a convolution
 // whose input tensor was not measured by its producers (misc.hip)
 hipError_t launch_range_amax(const float* x, long pixels, int C, int Cs, unsigned* slot, hipStream_t st);
-hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st);      // the slots' sub-slot words back to zero (start of every run)
+hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st);      // every slot back to zero (start of every run)
+hipError_t launch_range_fold(unsigned* slot, unsigned* rflag, int op_index, hipStream_t st);      // word 0 of a slot = the maximum of its partial words; reports a non-finite one
 hipError_t launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t st);      // flat device-to-device copy (one kernel, 16-byte accesses)
 hipError_t launch_conv_narrow(const ConvParams& p, hipStream_t st);   // Cout_store == 4, plain conv, no dual output
 hipError_t launch_score_fuse_lowres(const float* left, int lCs, const float* right, int rCs, const float* cw,

@@ -957,19 +957,42 @@ __global__ __launch_bounds__(256) void range_amax_kernel(const float* __restrict
     range_note_block(slot, m, blockIdx.x);
 }
 
-// The plan's slots back to zero at the start of a run: the RANGE_SUB words of every slot that are ever written.  (A kernel of its own,
-// not hipMemsetAsync: as a node of a captured graph the runtime's memset filled parts of the table with a stale 16-byte pattern on
-// some replays -- two device pointers alternating, surviving from run to run -- which the readers then took for a NaN range.)
-__global__ __launch_bounds__(256) void range_clear_kernel(unsigned* table, int n_sub)
+// The plan's slots back to zero at the start of a run.  (A kernel of its own, not hipMemsetAsync: as a node of a captured graph the
+// runtime's memset filled parts of the table with a stale 16-byte pattern on some replays -- two device pointers alternating, surviving
+// from run to run -- which the readers then took for a NaN range.)
+__global__ __launch_bounds__(256) void range_clear_kernel(uint4* table, long n16)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_sub) table[(size_t)(i / RANGE_SUB) * RANGE_WORDS + (size_t)(i % RANGE_SUB) * RANGE_STRIDE] = 0u;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) table[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st)
 {
-    const int n_sub = n_slots * RANGE_SUB;
-    if (n_sub > 0) hipLaunchKernelGGL(range_clear_kernel, dim3(cdiv(n_sub, 256)), dim3(256), 0, st, table, n_sub);
+    const long n16 = (long)n_slots * RANGE_WORDS / 4;
+    if (n16 > 0) hipLaunchKernelGGL(range_clear_kernel, dim3(cdiv(n16, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(table), n16);
+    return hipGetLastError();
+}
+
+// word 0 of a slot = the maximum of its partial words (and of what word 0 held): one block, in front of the first reader after a write.
+// A non-finite maximum is reported here, once: the host-mapped flag gets the reader's op index + 1 and what was seen (ACCEL_ERR_RANGE).
+__global__ __launch_bounds__(256) void range_fold_kernel(unsigned* slot, unsigned* rflag, int op_index)
+{
+    __shared__ unsigned sm[4];
+    const uint4 v = reinterpret_cast<const uint4*>(slot + RANGE_PART_OFF)[threadIdx.x];      // RANGE_PART = 4 x 256
+    unsigned m = range_wave_max(max(max(v.x, v.y), max(v.z, v.w)));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(max(sm[0], sm[1]), max(sm[2], sm[3])), slot[0]);
+        slot[0] = m;
+        if (m >= 0x7F800000u && rflag && atomicCAS(rflag, 0u, (unsigned)op_index + 1u) == 0u) { rflag[1] = m; __threadfence_system(); }
+    }
+}
+
+hipError_t launch_range_fold(unsigned* slot, unsigned* rflag, int op_index, hipStream_t st)
+{
+    static_assert(RANGE_PART == 1024, "range_fold_kernel reads four words per thread");
+    hipLaunchKernelGGL(range_fold_kernel, dim3(1), dim3(256), 0, st, slot, rflag, op_index);
     return hipGetLastError();
 }
 

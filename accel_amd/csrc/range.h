@@ -1,22 +1,29 @@
 // Range slots of the fp16x2 form (kernels.h ConvParams::xr / yr): how a convolution learns the largest |pixel| of the
 // tensor it reads IN THE RUN THAT USES IT, without a pass over that tensor.
 //
-// Writers: every kernel that stores a tensor some fp16x2-form convolution reads keeps the running maximum of the bit patterns of
-// |value| over what it stored (non-negative floats order like their bit patterns; a NaN sorts above infinity and stays visible),
-// reduces it over the wavefront (or the block) and raises the tensor's slot with ONE atomicMax.  Same-address atomics serialise at
-// 11 ns each on MI355X (scripts/microbench/amax_ubench.hip: 262 144 of them cost 2.9 ms), so a slot is RANGE_SUB sub-slots 256 bytes
-// apart -- different memory channels: 65 536 atomics per launch are free, 262 144 cost 75 us -- and a writer picks one by its
-// block / wavefront index.  The maximum is order-independent: the slot's final content is a function of the tensor alone.
-// Reader: the maximum over the sub-slots (one load per lane, five cross-lane steps), then the power of two that puts it into
-// [2^13, 2^14): 4x of headroom to the largest half (the Winograd kernels spend it on their input transform's growth), full relative
-// precision (two half terms, 22-23 bits) for every pixel down to 2^-17 of the largest.
-// The plan zeroes its slots at the start of every run (one memset node in the captured graph).
+// A slot is one word the READER takes (word 0) and RANGE_PART partial words the WRITERS raise.
+// Writers: every kernel that stores a tensor some fp16x2-form convolution reads computes the largest bit pattern of |value| over
+// what it stored (non-negative floats order like their bit patterns; a NaN sorts above infinity and stays visible), reduces it over the
+// block (or the wavefront) and raises ONE partial word -- picked by its block index -- with an atomicMax.  Same-address atomics
+// serialise at 11 ns each on MI355X (scripts/microbench/amax_ubench.hip: 262 144 of them cost 2.9 ms), so the 16 384 blocks of a res2
+// layer must not meet on one word; spread over 1024 words on different lines they cost nothing.  The maximum is order-independent:
+// the slot's content is a function of the tensor alone.
+// Fold: a one-block kernel (misc.hip range_fold_kernel) in front of the first reader after a write takes the maximum of the partial
+// words into word 0.
+// Reader: ONE scalar load, then the power of two that puts the largest pixel into [2^13, 2^14): 4x of headroom to the largest half
+// (the Winograd kernels spend it on their input transform's growth), full relative precision (two half terms, 22-23 bits) for every
+// pixel down to 2^-17 of the largest.  (Measured on the way here, same-box A/B of the headline, scripts/ab_round.sh: readers that took
+// the maximum over 32 spread sub-slots themselves cost 4.3 ms of a 62 ms step as scalar loads -- 32 serialised scalar-cache misses
+// per CU and launch -- and 20 % on the short-K layers as one vector load per lane; writers whose bookkeeping was woven into the store
+// loop cost 30-40 registers per lane and a resident block.)
+// The plan zeroes its slots at the start of every run (a kernel of its own: a hipMemsetAsync node of a captured graph filled parts
+// of the table with a stale 16-byte pattern on some replays).
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define RANGE_SUB 32
-#define RANGE_STRIDE 64                          // words between sub-slots (256 bytes)
-#define RANGE_WORDS (RANGE_SUB * RANGE_STRIDE)   // words of one slot
+#define RANGE_PART 1024                          // partial words of a slot
+#define RANGE_PART_OFF 64                        // ... starting 256 bytes behind word 0
+#define RANGE_WORDS (RANGE_PART_OFF + RANGE_PART)   // words of one slot
 
 __device__ __forceinline__ unsigned range_abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
 
@@ -30,16 +37,22 @@ __device__ __forceinline__ unsigned range_wave_max(unsigned u)
     return u;
 }
 
-// one atomic per wavefront; `key`: any index that differs between the wavefronts of a launch (spreads them over the sub-slots)
+// one atomic per wavefront; `key`: any index that differs between the wavefronts of a launch (spreads them over the partial words)
 __device__ __forceinline__ void range_note_wave(unsigned* slot, unsigned m, unsigned key)
 {
+#ifdef RANGE_AB_NO_NOTE
+    return;
+#endif
     m = range_wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + (key & (RANGE_SUB - 1)) * RANGE_STRIDE, m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + RANGE_PART_OFF + (key & (RANGE_PART - 1)), m);
 }
 
 // one atomic per block (byte movers with hundreds of thousands of wavefronts per launch).  Every thread of the block must call it.
 __device__ __forceinline__ void range_note_block(unsigned* slot, unsigned m, unsigned key)
 {
+#ifdef RANGE_AB_NO_NOTE
+    return;
+#endif
     __shared__ unsigned range_sm[16];
     m = range_wave_max(m);
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -47,28 +60,29 @@ __device__ __forceinline__ void range_note_block(unsigned* slot, unsigned m, uns
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < nw; ++w) m = range_sm[w] > m ? range_sm[w] : m;
-        if (m) atomicMax(slot + (key & (RANGE_SUB - 1)) * RANGE_STRIDE, m);
+        if (m) atomicMax(slot + RANGE_PART_OFF + (key & (RANGE_PART - 1)), m);
     }
     __syncthreads();      // a second call may follow: range_sm is read by thread 0 above
 }
 
-// the slot's value: wave-uniform (every lane of the wavefront must call it)
-__device__ __forceinline__ unsigned range_read(const unsigned* slot)
+// the slot's value (after the fold): one scalar load (the address is uniform and the kernel has written nothing yet).  Same-box A/B of
+// the headline (scripts/ab_round.sh): as an agent-scope vector load of the same word 71 ms per step against 67.
+__device__ __forceinline__ unsigned range_read(const unsigned* __restrict__ slot)
 {
-    unsigned u = slot[(threadIdx.x & (RANGE_SUB - 1)) * RANGE_STRIDE];
-#pragma unroll
-    for (int o = RANGE_SUB / 2; o; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)u, o);
-        u = t > u ? t : u;
-    }
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)u);
+#ifdef RANGE_AB_NO_READ      // timing experiments only (scripts/ab_round.sh): WRONG results
+    return 0x42000000u;
+#endif
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)slot[0]);
 }
 
 // largest |x| (bit pattern) -> s = 2^e with s * largest in [2^13, 2^14) and 1 / s; an all-zero tensor: 1
 struct RangeScale { float s, inv; };
 __host__ __device__ __forceinline__ RangeScale range_scale(unsigned bits)
 {
-    int e = 140 - (int)((bits >> 23) & 0xFFu);      // largest = m 2^(E - 126), m in [0.5, 1)
+#ifndef RANGE_TOP_EXP
+#define RANGE_TOP_EXP 14      // the largest pixel lands in [2^(RANGE_TOP_EXP - 1), 2^RANGE_TOP_EXP)
+#endif
+    int e = (126 + RANGE_TOP_EXP) - (int)((bits >> 23) & 0xFFu);      // largest = m 2^(E - 126), m in [0.5, 1)
     e = e > 100 ? 100 : (e < -100 ? -100 : e);
     if (!bits) e = 0;
     RangeScale r;
@@ -78,16 +92,11 @@ __host__ __device__ __forceinline__ RangeScale range_scale(unsigned bits)
     return r;
 }
 
-// prologue of an fp16x2-form convolution: the scale pair of its input slot (null: 1); a non-finite range is reported once per
-// launch through the host-mapped flag
-__device__ __forceinline__ RangeScale range_prologue(const unsigned* xr, unsigned* rflag, int op_index)
+// prologue of an fp16x2-form convolution: the scale pair of its input slot (null: 1).  (A non-finite range is reported by the fold
+// kernel, not here: the branch with its system-scope atomic in the prologue of the hot kernels cost 2.2 ms of a 63 ms step.)
+__device__ __forceinline__ RangeScale range_prologue(const unsigned* xr)
 {
     RangeScale one; one.s = 1.f; one.inv = 1.f;
     if (!xr) return one;
-    const unsigned bits = range_read(xr);
-    if (bits >= 0x7F800000u && rflag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        if (atomicCAS(rflag, 0u, (unsigned)op_index + 1u) == 0u) rflag[1] = bits;      // first offender: its index and what it saw
-        __threadfence_system();
-    }
-    return range_scale(bits);
+    return range_scale(range_read(xr));
 }

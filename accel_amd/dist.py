@@ -228,3 +228,88 @@ class FrameGather(object):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
+
+
+class ScoreGather(object):
+    """The per-frame gather at SCORE resolution (accel_gather_scores of include/accel_hip.h): every rank sends the fused
+    score maps its plans leave in the model's `scores` buffer (B x H/16 x W/16 x 20 fp32: 0.66 MB per 1024x2048 frame instead of the
+    159 MB of fp32 logits), the root expands every block into logits + labels with the launch its own plans end with -- bit-identical to
+    what the peer computed -- on the communication stream, beside the next frame's compute.  What each peer's xGMI link carries drops
+    256x; what remains on the root is the HBM write of the expanded logits (the same bytes a logits gather would have landed there).
+
+    Needs uniform upsampling filters (the reference freezes them: accel_18.py:153): `available(model)` says whether the model has a
+    `scores` buffer; use FrameGather("logits") otherwise.  On a GPU the C-ABI transport is the only one (collective decision as in
+    FrameGather); backend_device="cpu" is the gloo path of the tests: scores through torch.distributed.gather, expansion through
+    model.expand_scores_host."""
+
+    @staticmethod
+    def available(model):
+        return bool(getattr(model, "has_buffer", lambda n: False)("scores"))
+
+    def __init__(self, model, ctx, B, H, W, device, group=None, own_images=None, ncls=19, backend_device="cuda", emulate_peers=0):
+        """emulate_peers = k (one-GPU measurements, world size 1): the root also expands k more blocks per frame -- its own maps again,
+        into the image slots k peers would fill -- so that the expansion work of an N = k + 1 job runs beside its compute"""
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.emulate = int(emulate_peers)
+        self.model, self.ctx, self.group = model, ctx, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.B, self.own = int(B), int(B if own_images is None else own_images)
+        if self.own != self.B and self.rank != 0:
+            raise ValueError("only the root may contribute fewer images than a slot holds")
+        self.on_cuda = backend_device == "cuda"
+        self.map_shape = (H // 16, W // 16, (ncls + 3) // 4 * 4)
+        self.n, self.comm = 0, None
+        dev = "cuda:%d" % device if self.on_cuda else "cpu"
+        self.transport = "cabi" if self.on_cuda else "torch"
+        root = self.rank == 0
+        self.recv = [torch.empty((self.world, self.B) + self.map_shape, dtype=torch.float32, device=dev) for _ in range(2)] if root else [None, None]
+        if self.on_cuda:
+            _vote_any(True, ctx, group)      # (the same two collective rounds as FrameGather: every rank requires the C-ABI transport)
+            self.comm = make_comm(ctx, group)
+            nimg = (self.world + self.emulate) * self.B
+            self.logits = torch.empty((nimg, ncls, H, W), dtype=torch.float32, device=dev) if root else None
+            self.labels = torch.empty((nimg, H, W), dtype=torch.uint8, device=dev) if root else None
+            return
+        self.stage = [torch.empty((self.B,) + self.map_shape, dtype=torch.float32) for _ in range(2)]
+        self.work = [None, None]
+        self.logits = self.labels = None
+
+    def submit(self):
+        s = self.n & 1
+        if self.comm is not None:
+            r = self.rank == 0
+            self.comm.gather_scores(self.model, self.own, self.B, self.recv[s].data_ptr() if r else None,
+                                    self.logits.data_ptr() if r else None, self.labels.data_ptr() if r else None, 0)
+            for k in range(self.emulate if r else 0):
+                at = (self.world + k) * self.B
+                self.model.expand_scores(self.recv[s].data_ptr(), self.B, self.logits[at].data_ptr(), self.labels[at].data_ptr(), comm=self.comm)
+        else:
+            if self.work[s] is not None:
+                self.work[s].wait()
+            self.stage[s].copy_(self.torch.from_numpy(self.model.read("scores", tuple(self.stage[s].shape), np.float32)))
+            self.work[s] = self.dist.gather(self.stage[s], [self.recv[s][r] for r in range(self.world)] if self.rank == 0 else None,
+                                            dst=0, group=self.group, async_op=True)
+        self.n += 1
+        return s
+
+    def expanded(self, slot):
+        """Root, CPU path: (logits, labels) of every rank's block of `slot`, expanded by the model (GPU path: self.logits / self.labels
+        after drain())"""
+        self.work[slot].wait()
+        return [self.model.expand_scores_host(self.recv[slot][r].numpy()) for r in range(self.world)]
+
+    def drain(self):
+        if self.comm is not None:
+            self.comm.sync()
+            return
+        for s in (0, 1):
+            if self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None

@@ -78,6 +78,8 @@ def _declare(lib):
         "accel_comm_destroy": [vp],
         "accel_gather_logits": [vp, vp, vp, sz, i],
         "accel_gather_frames": [vp, vp, sz, vp, sz, i],
+        "accel_expand_scores": [vp, vp, i, vp, vp, vp],
+        "accel_gather_scores": [vp, vp, i, i, vp, vp, vp, i],
         "accel_comm_sync": [vp],
         "accel_key_forward": [vp, vp, i, vp, vp, vp, i],
         "accel_cur_forward": [vp, vp, vp, i, vp, vp, vp, i],
@@ -315,6 +317,11 @@ class Comm(object):
             check(lib().accel_gather_frames(self.handle, ctypes.c_void_p(send_ptr), int(send_bytes),
                                             ctypes.c_void_p(recv_ptr) if recv_ptr else None, int(nbytes), int(root)))
 
+    def gather_scores(self, model, own_images, slot_images, recv_scores=None, logits_out=None, labels_out=None, root=0):
+        """accel_gather_scores: every rank's fused score maps to the root, expanded there into logits + labels (device pointers; None on peers)"""
+        vp = lambda p: ctypes.c_void_p(p) if p else None
+        check(lib().accel_gather_scores(self.handle, model.handle, int(own_images), int(slot_images), vp(recv_scores), vp(logits_out), vp(labels_out), int(root)))
+
     def sync(self):
         check(lib().accel_comm_sync(self.handle))
 
@@ -430,6 +437,15 @@ class Model(object):
     def read_device(self, buf, dev_ptr, nbytes):
         """enqueue a D2D copy of a persistent buffer into caller-owned HBM (no host sync)"""
         check(lib().accel_model_read(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
+
+    def expand_scores(self, scores_ptr, n_images, logits_ptr, labels_ptr, comm=None):
+        """accel_expand_scores: logits + labels of n_images fused score maps (device pointers) by the model's own last launch"""
+        check(lib().accel_expand_scores(self.handle, ctypes.c_void_p(scores_ptr), int(n_images), ctypes.c_void_p(logits_ptr), ctypes.c_void_p(labels_ptr),
+                                        comm.handle if comm is not None else None))
+
+    def has_buffer(self, buf):
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        return lib().accel_model_buffer(self.handle, buf.encode(), ctypes.byref(ptr), ctypes.byref(n)) == 0
 
     def buffer(self, buf):
         ptr, n = ctypes.c_void_p(), ctypes.c_size_t()

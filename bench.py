@@ -41,7 +41,11 @@ def parse():
     ap.add_argument("--version", default="18")
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--interval", type=int, default=5)
-    ap.add_argument("--gather", default="logits", choices=["logits", "labels", "none"])
+    ap.add_argument("--gather", default="scores", choices=["scores", "logits", "labels", "none"],
+                    help="N > 1: what every rank sends to rank 0 per frame.  scores (default): the fused score maps (0.66 MB per 1024x2048 frame), "
+                         "expanded on the root into the same fp32 logits + labels bit for bit (accel_gather_scores; falls back to logits when the "
+                         "model's upsampling filters are not uniform); logits: the 159 MB fp32 logits themselves (link-bound beyond ~480 frames/s "
+                         "per GPU, DESIGN.md 6); labels: the uint8 label maps")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "8")),
                     help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
                          "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
@@ -53,9 +57,10 @@ def parse():
     ap.add_argument("--secondary", default="auto", choices=["auto", "none"],
                     help="auto: on a single GPU with the headline configuration also measure Accel-101, batch 1 and the "
                          "PCIe-inclusive loop (reported under `secondary`); none: headline only")
-    ap.add_argument("--root-relief", type=int, default=int(os.environ.get("ACCEL_BENCH_ROOT_RELIEF", "0")),
-                    help="N > 1 with --gather logits: rank 0 (which also receives every other rank's frames) processes this many clips "
-                         "fewer per call than the other ranks (dist.shard_clips(..., root_relief)); 0 = even shares")
+    ap.add_argument("--root-relief", type=int, default=int(os.environ.get("ACCEL_BENCH_ROOT_RELIEF", "-1")),
+                    help="N > 1 with --gather scores | logits: rank 0 (which also receives -- and with scores expands -- every other rank's frames) "
+                         "processes this many clips fewer per call than the other ranks (dist.shard_clips(..., root_relief)); 0 = even shares; "
+                         "default (-1): 1")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, have each print its rank / world size, exit (no GPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -441,17 +446,29 @@ def _gather_self_secondary(wl, a, B, H, W, local_rank, steps, warm, rate):
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
             made = True
         os.environ["ACCEL_GATHER_SELF_SENDRECV"] = "1"
-        for what, shape, dt, per_frame in (("logits", (B, 19, H, W), "f4", 19 * H * W * 4), ("labels", (B, H, W), "u1", H * W)):
+        for what, shape, dt, per_frame in (("scores", None, None, (H // 16) * (W // 16) * 20 * 4), ("scores_root_of_8", None, None, (H // 16) * (W // 16) * 20 * 4),
+                                           ("logits", (B, 19, H, W), "f4", 19 * H * W * 4), ("labels", (B, H, W), "u1", H * W)):
             name = "accel18_batch%d_gather_self_%s" % (B, what)
             try:
-                wl.gather = adist.FrameGather(wl.model, wl.model.ctx, what, shape, dt, local_rank, transport="cabi")
+                if what.startswith("scores"):
+                    if not adist.ScoreGather.available(wl.model):
+                        out[name] = {"error": "the model has no `scores` buffer (upsampling filters not uniform)"}
+                        continue
+                    wl.gather = adist.ScoreGather(wl.model, wl.model.ctx, B, H, W, local_rank, emulate_peers=7 if what == "scores_root_of_8" else 0)
+                else:
+                    wl.gather = adist.FrameGather(wl.model, wl.model.ctx, what, shape, dt, local_rank, transport="cabi")
                 el = wl.timed(steps, warm)
                 v = rate(wl, el, steps)
                 out[name] = {"value": v, "unit": "frames/s", "payload_bytes_per_call": per_frame * B,
                              "peer_link_gbps_at_this_rate": round(per_frame * v / 1e9, 2),
-                             "what": "headline loop + per-frame gather of %s through ncclSend / ncclRecv to self on the communication stream "
-                                     "(compute-side cost of the collective; peer_link_gbps_at_this_rate = what ONE peer's xGMI link to the root "
-                                     "would have to carry at this frame rate)" % what}
+                             "what": ("headline loop + per-frame gather of the fused score maps through ncclSend / ncclRecv to self and their expansion into "
+                                      "fp32 logits + labels on the communication stream: what a PEER pays" if what == "scores" else
+                                      "the same with the root's work of an 8-GPU job: besides its own block the expansion of SEVEN more blocks per call "
+                                      "(%.1f GB of logits written per call on the communication stream beside the next frame's kernels): what the ROOT pays"
+                                      % (7 * B * 19 * H * W * 4 / 1e9) if what == "scores_root_of_8" else
+                                      "headline loop + per-frame gather of %s through ncclSend / ncclRecv to self on the communication stream "
+                                      "(compute-side cost of the collective)" % what) +
+                                     "; peer_link_gbps_at_this_rate = what ONE peer's xGMI link to the root would have to carry at this frame rate"}
             except Exception as e:
                 out[name] = {"error": repr(e)}
             finally:
@@ -507,20 +524,32 @@ def _run(a):
     config.SCALES[0] = (H, W)
 
     # the root of the logits gather also receives every other rank's frames: --root-relief gives it that many clips fewer per call
-    relief = min(max(0, a.root_relief), B - 1) if (world > 1 and a.gather == "logits") else 0
+    relief = min(a.root_relief if a.root_relief >= 0 else 1, B - 1) if (world > 1 and a.gather in ("logits", "scores")) else 0
     B_rank = B - relief if rank == 0 else B
     wl = Workload(a.version, B_rank, H, W, a.interval, local_rank, rank, config)
 
     gather_note = "none (single GPU)"
+    payload = a.gather
     if (world > 1 or force_dist) and a.gather != "none":
         try:
-            if a.gather == "logits":
+            if payload == "scores":
+                # every rank looks at its own model and the ranks agree (the models are replicas; a disagreement must not split the job)
+                ok = torch.tensor([1 if adist.ScoreGather.available(wl.model) else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) != 1:
+                    payload = "logits"
+            if payload == "scores":
+                wl.gather = adist.ScoreGather(wl.model, wl.model.ctx, B, H, W, local_rank, own_images=B_rank)
+            elif payload == "logits":
                 wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank,
                                               own_bytes=B_rank * 19 * H * W * 4 if B_rank != B else None)
             else:
                 wl.gather = adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank)
+            note = getattr(wl.gather, "transport_note", "")
             gather_note = "RCCL gather of per-frame %s to rank 0, async, double-buffered, transport %s%s" % (
-                a.gather, wl.gather.transport, ("; " + wl.gather.transport_note) if wl.gather.transport_note else "")
+                payload + (" (fused score maps, expanded on the root into fp32 logits + labels, bit-identical)" if payload == "scores" else
+                           " (asked for scores: the model has no `scores` buffer)" if a.gather == "scores" else ""),
+                wl.gather.transport, ("; " + note) if note else "")
         except Exception as e:   # keep the bench alive; the JSON says what happened
             wl.gather = None
             gather_note = "disabled: %r" % (e,)
@@ -555,23 +584,24 @@ def _run(a):
     # N > 1: the same steps once more with the OTHER payload of the gather (uint8 label maps are 76x smaller than fp32
     # logits), so the line shows what the collective costs; and the rate each peer's xGMI link to the root carries
     gather_detail = None
-    if world > 1 and a.gather in ("logits", "labels") and wl.gather is not None and not gather_failures:
-        other = "labels" if a.gather == "logits" else "logits"
+    if world > 1 and a.gather in ("scores", "logits", "labels") and wl.gather is not None and not gather_failures:
+        other = "logits" if payload != "logits" else "labels"
         try:
             wl.sync()
             wl.gather.close()
             wl.gather = (adist.FrameGather(wl.model, wl.model.ctx, "labels", (B, H, W), "u1", local_rank,
                                            own_bytes=B_rank * H * W if B_rank != B else None) if other == "labels"
-                         else adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank))
+                         else adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank,
+                                                own_bytes=B_rank * 19 * H * W * 4 if B_rank != B else None))
             el2 = wl.timed(a.steps, 1, dist)
             t2 = torch.tensor([el2], dtype=torch.float64, device="cuda")
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             el2 = float(t2.item())
-            per_frame = {"logits": 19 * H * W * 4, "labels": H * W}
+            per_frame = {"logits": 19 * H * W * 4, "labels": H * W, "scores": (H // 16) * (W // 16) * 20 * 4}
             fps = lambda el: (world * B - relief) * a.steps * a.interval / el
             gather_detail = {
-                "gather_" + a.gather: {"value": round(fps(elapsed), 2), "unit": "frames/s",
-                                       "peer_link_gbps": round(per_frame[a.gather] * fps(elapsed) / world / 1e9, 2)},
+                "gather_" + payload: {"value": round(fps(elapsed), 2), "unit": "frames/s",
+                                      "peer_link_gbps": round(per_frame[payload] * fps(elapsed) / world / 1e9, 2)},
                 "gather_" + other: {"value": round(fps(el2), 2), "unit": "frames/s",
                                     "peer_link_gbps": round(per_frame[other] * fps(el2) / world / 1e9, 2)},
                 "note": "every peer sends its frames over its own direct xGMI link to rank 0 (about 153 GB/s per link and direction); "

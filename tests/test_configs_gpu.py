@@ -29,6 +29,28 @@ def _oracle_frames(frames_bgr, cfg):
     return [image.transform(f, cfg.network.PIXEL_MEANS).astype(np.float32) for f in frames_bgr]
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_clip(P, version, frames_bgr, cfg, interval):
+    """oracle.graphs.run_clip, remembered per (model, frames, interval) for the session: tests that look at the same clip from several
+    sides (the three forced Winograd geometries; config 2 and image 0 of config 4) share ONE oracle evaluation -- the suite has to fit
+    the driver's time limit (round 4: 1081 of 1200 s).  A longer run of the same clip serves a shorter one (frame t depends on frames <= t)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in frames_bgr:
+        h.update(np.ascontiguousarray(f).tobytes())
+    key = (str(version), frames_bgr[0].shape, interval)
+    for (k, n, digests), ref in _ORACLE_RUNS.items():
+        if k == key and n >= len(frames_bgr) and digests[:len(frames_bgr)] == tuple(hashlib.sha1(np.ascontiguousarray(f).tobytes()).hexdigest() for f in frames_bgr):
+            out = G.ClipResult(ref[:len(frames_bgr)])
+            out.critical = ref.critical[:len(frames_bgr)]
+            return out
+    ref = G.run_clip(P, str(version), _oracle_frames(frames_bgr, cfg), interval)
+    _ORACLE_RUNS[(key, len(frames_bgr), tuple(hashlib.sha1(np.ascontiguousarray(f).tobytes()).hexdigest() for f in frames_bgr))] = ref
+    return ref
+
+
 @pytest.mark.parametrize("interval", [1, 2])
 def test_config1_accel18_512x1024_pair(demo_cfg, interval):
     """dff_deeplab demo on a 2-frame 512x1024 pair.  interval 1: `idx % 1 == 0` makes both frames key frames
@@ -46,7 +68,7 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
         tester.release_models()
     P = dict(arg)
     P.update(aux)
-    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    ref = _oracle_clip(P, "18", frames, demo_cfg, interval)
     check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
 
 
@@ -88,7 +110,7 @@ def test_winograd_bf16_geometry_on_every_eligible_layer_vs_oracle(demo_cfg, monk
         tester.release_models()
     P = dict(arg)
     P.update(aux)
-    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    ref = _oracle_clip(P, "18", frames, demo_cfg, interval)
     check_against_oracle(outs, ref, "accel-18 512x1024 every eligible layer on geometry %d" % geometry)
 
 
@@ -105,7 +127,8 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkey
     monkeypatch.setenv("ACCEL_ARENA_NO_REUSE", "1")
     demo_cfg.SCALES[0] = (H, W)
     arg, aux = synth.model_params("18", H, W, demo_cfg)
-    clips = [synth.make_clip(H, W, interval, seed=4100 + b) for b in range(B)]
+    # clip 0 is the clip of test_config2_* (its first two frames: key + non-key under both schedules), so that the oracle's evaluation of it is shared
+    clips = [synth.make_clip(H, W, 3)[:interval]] + [synth.make_clip(H, W, interval, seed=4100 + b) for b in range(1, B)]
     per_clip = [demo.build_batches(c, demo_cfg) for c in clips]
     try:
         single = [[None] * interval for _ in range(B)]
@@ -145,7 +168,7 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkey
     # M = 8x the rows, other table entries than the one-clip bind) must meet the same bar as a one-clip run does
     P = dict(arg)
     P.update(aux)
-    ref = G.run_clip(P, "18", _oracle_frames(clips[0], demo_cfg), interval)
+    ref = _oracle_clip(P, "18", clips[0], demo_cfg, 3)      # (interval 3 = config 2's schedule: frames 0, 1 are key, non-key as here)
     check_against_oracle(image0, ref, "config4 accel-18 1024x2048, image 0 of the 8-clip call")
 
 
@@ -163,7 +186,7 @@ def test_config2_accel18_1024x2048_vs_oracle(demo_cfg, monkeypatch):
     frames = synth.make_clip(H, W, 3)
     P = dict(arg)
     P.update(aux)
-    ref = G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), interval)
+    ref = _oracle_clip(P, "18", frames, demo_cfg, interval)
     for mode in ("1", "0"):
         monkeypatch.setenv("ACCEL_FOLD_LINEAR", mode)
         try:
@@ -304,6 +327,49 @@ def test_config4_rccl_gather_on_one_gpu(demo_cfg, transport, monkeypatch):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("sendrecv", [False, True])
+def test_config4_score_gather_expands_to_the_peers_own_logits(demo_cfg, sendrecv, monkeypatch):
+    """The default payload of the multi-GPU gather (accel_gather_scores): the fused score maps of a frame travel, the root expands them.
+    On one GPU (world of one; with ACCEL_GATHER_SELF_SENDRECV the block goes through ncclSend / ncclRecv to itself): over a key and
+    three non-key frames at 1024x2048 the EXPANDED logits and labels must be bit-identical to the logits / labels the model itself
+    left in its buffers, also in the image slots of an emulated second and third peer (accel_expand_scores on the communication stream)."""
+    import torch
+    import torch.distributed as dist
+    from accel_amd import demo, dist as adist
+    from accel_amd.core import tester
+    if sendrecv:
+        monkeypatch.setenv("ACCEL_GATHER_SELF_SENDRECV", "1")
+    H, W, interval = 1024, 2048, 4
+    demo_cfg.SCALES[0] = (H, W)
+    arg, aux = synth.model_params("18", H, W, demo_cfg)
+    frames = synth.make_clip(H, W, 4)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        data = demo.build_batches(frames, demo_cfg)
+        r = demo.ClipRunner("18", demo_cfg, arg, aux, (H, W))
+        m = r.key_predictor._model
+        r.step(0, data[0], interval)                     # binds the key plan: the `scores` buffer exists from here on
+        assert adist.ScoreGather.available(m)
+        g = adist.ScoreGather(m, m.ctx, 1, H, W, 0, emulate_peers=2)
+        assert g.transport == "cabi" and g.recv[0].shape == (1, 1, H // 16, W // 16, 20)
+        for t in range(4):
+            lg, lab = r.step(t, data[t], interval)
+            g.submit()
+            g.drain()
+            want, wlab = lg.asnumpy(), np.uint8(lab.asnumpy())
+            got, glab = g.logits.cpu().numpy(), g.labels.cpu().numpy()
+            for k in range(3):                           # the root's own slot and the two emulated peers'
+                np.testing.assert_array_equal(got[k:k + 1], want, err_msg="frame %d, image slot %d" % (t, k))
+                np.testing.assert_array_equal(glab[k:k + 1], wlab.reshape(1, H, W))
+        g.close()
+    finally:
+        tester.release_models()
+        dist.destroy_process_group()
+
+
 def test_cabi_gather_without_torch_distributed(ctx):
     """accel_comm_* / accel_gather_logits stand-alone (a C host would do exactly this): one rank, the root's receive
     buffer must hold the send buffer's bytes; the send buffer may be overwritten right after the call returns."""
@@ -377,9 +443,9 @@ def test_gather_beside_the_next_frames_compute_does_not_disturb_it(demo_cfg, mon
 
 
 def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
-    """Accel-50, fp16-MFMA convolutions, 2048x4096 (config 5's frame size), the first three frames of a kf=10 group
-    (key, non-key, non-key: the chain through warp + correction branch).  Checked against the fp32 run of the same
-    clip on the same path: logits finite, mean error small against the logit range, labels agree on >= 99 %."""
+    """Accel-50, fp16-MFMA convolutions with half activation storage, 2048x4096 (config 5's frame size), the first three frames of a
+    kf=10 group (key, non-key, non-key: the chain through warp + correction branch): finite logits, non-degenerate label maps, and the
+    key + first non-key frame against the mode's own specification (below)."""
     from accel_amd import demo
     from accel_amd.core import tester
     H, W, interval = 2048, 4096, 10
@@ -387,21 +453,18 @@ def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     arg, aux = synth.model_params("50", H, W, demo_cfg)
     frames = synth.make_clip(H, W, 3)
     outs = {}
-    for dt in ("f32", "f16"):
-        monkeypatch.setenv("ACCEL_CONV_DTYPE", dt)
-        try:
-            res = demo.run_clip("50", demo_cfg, arg, aux, frames, interval)
-            outs[dt] = [(lg[0][:, ::4, ::4].copy(), lab.copy()) for lg, lab in res]    # keep 1/16 of the logits
-            del res
-        finally:
-            tester.release_models()
-    for t, ((a, la), (b, lb)) in enumerate(zip(outs["f32"], outs["f16"])):
+    monkeypatch.setenv("ACCEL_CONV_DTYPE", "f16")
+    try:
+        res = demo.run_clip("50", demo_cfg, arg, aux, frames, interval)
+        outs["f16"] = [(lg[0][:, ::4, ::4].copy(), lab.copy()) for lg, lab in res]    # keep 1/16 of the logits
+        del res
+    finally:
+        tester.release_models()
+    for t, (b, lb) in enumerate(outs["f16"]):
         assert np.isfinite(b).all(), "frame %d: non-finite fp16-mode logits" % t
-        scale = max(1.0, float(np.abs(a).max()))
-        assert float(np.abs(a - b).max()) <= 0.1 * scale, "frame %d" % t
-        assert float(np.abs(a - b).mean()) <= 1e-2 * scale, "frame %d" % t
-        assert float((la != lb).mean()) < 1e-2, "frame %d" % t
-        assert len(np.unique(la)) > 1
+        assert len(np.unique(lb)) > 1
+    # (rounds 3-4 also compared with the fp32 run of the same clip on the same path: 50 s of the suite for a weaker statement than the
+    # one below; the fp32 path itself is checked against the oracle at this model in test_accel34_accel50_1024x2048_vs_oracle)
     # ... and against the mode's own SPECIFICATION at config 5's frame size: the oracle on half-rounded operands with the stored tensors
     # rounded once more (oracle.graphs ROUND_F16 + STORE_F16 = the layers the lowering stores as half), key frame + first non-key frame.
     # Two evaluations of ~100 discontinuous roundings decorrelate down to the half-precision noise (tests/test_f16_storage_gpu.py), so the

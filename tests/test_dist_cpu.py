@@ -146,6 +146,63 @@ def test_gather_logits_world2_gloo():
     assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4, 5]
 
 
+class _FakeScoreModel(object):
+    """stands in for runtime.Model: a `scores` buffer per rank and the expansion rule (here: every score repeated 2 x 2)"""
+
+    def __init__(self, rank):
+        self.rank, self.frame = rank, 0
+
+    def produce(self, shape):
+        self.frame += 1
+        self.cur = (np.arange(np.prod(shape), dtype=np.float32).reshape(shape) % 7) + 100.0 * self.rank + self.frame
+
+    def read(self, name, shape, dtype):
+        assert name == "scores"
+        return self.cur.reshape(shape).astype(dtype)
+
+    @staticmethod
+    def expand_scores_host(maps):
+        return np.repeat(np.repeat(maps[..., :19], 2, axis=1), 2, axis=2)
+
+
+def _score_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, H, W = 2, 64, 96
+        model = _FakeScoreModel(rank)
+        g = adist.ScoreGather(model, None, B, H, W, 0, backend_device="cpu")
+        ok = True
+        for t in range(5):                               # both staging slots get reused
+            model.produce((B, H // 16, W // 16, 20))
+            slot = g.submit()
+            if rank == 0:
+                exp = g.expanded(slot)
+                for r in range(world):
+                    want = (np.arange(B * 4 * 6 * 20, dtype=np.float32).reshape(B, 4, 6, 20) % 7) + 100.0 * r + (t + 1)
+                    ok = ok and np.array_equal(exp[r], _FakeScoreModel.expand_scores_host(want)) and exp[r].shape == (B, 8, 12, 19)
+        g.drain()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_scores_world2_gloo():
+    """dist.ScoreGather (the default payload of the N > 1 bench): every rank's fused score maps arrive on rank 0 in rank order, frame by
+    frame, and are expanded there by the model's own rule"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_score_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
 def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment must start the two ranks itself (under
     torch.distributed.run on 127.0.0.1) -- never run one rank and report it as two.  --launch-check stops every rank
