@@ -178,6 +178,8 @@ struct accel_plan {
     int split = 1;
     unsigned* range = nullptr;
     int n_slots = 0;
+    std::map<int, int> slot_of;      // lowering buffer id -> slot index
+    std::vector<int> in_slot;        // per op: the slot a convolution with an fp16x2 form reads (-1: none)
     unsigned* range_flag = nullptr;       // host-mapped
     unsigned* range_flag_dev = nullptr;
     int n_h2 = 0;
@@ -1141,26 +1143,37 @@ static int range_check(accel_plan* p)
                 p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", bits, bits == 0x7F800000u ? "infinity" : "NaN");
 }
 
-// Range slots (kernels.h, range.h): which tensors need one, who raises it, who has to measure for himself.  Called once every op is
-// finalized (the fp16x2 forms are known) and before anything is launched.
+// Range slots (kernels.h, range.h): which tensors need one, who raises it, who has to measure for himself.
 //   * a slot per physical buffer some convolution WITH an fp16x2 form reads as its input (`xr=<id>` from the lowering; a convolution
-//     of a hand-written plan without an id gets a private slot);
-//   * every op that writes into such a buffer (`yr=` / `y2r=`) and has the range epilogue gets the slot's address;
-//   * a reader is marked `measure` unless at least one earlier op of the plan wrote its buffer and every such writer has the epilogue
-//     (persistent buffers written by another plan or by the host, tensors imported by import_nchw).
+//     of a hand-written plan without an id gets a private slot): assign_range_slots, once every op is finalized and before anything
+//     is launched (the tuner times the fp16x2 candidates);
+//   * resolve_range_flags, before and again AFTER the tuner has chosen the launch geometries: a reader counts only if the geometry it
+//     runs on executes the fp16x2 form; every op that writes into a buffer a counting reader reads (`yr=` / `y2r=`) and has the range
+//     epilogue gets the slot's address (the others get none: their epilogue does nothing); a counting reader is marked `measure`
+//     unless at least one earlier op of the plan wrote its buffer and every such writer has the epilogue (persistent buffers written
+//     by another plan or by the host, tensors imported by import_nchw), and `fold` if it is the first reader after a write.
+static bool conv_has_h2_form(const ConvParams& c) { return c.wh2r || c.wubh || c.wstemh; }
+static bool conv_runs_h2(const ConvParams& c)
+{
+    if (c.f16 || c.narrow) return false;
+    const int t = c.force_tile;
+    return ((t == CONV_TILE_WINO_B3 || t == CONV_TILE_WINO_B3U || t == CONV_TILE_WINO_B3S) && c.wubh) || (t == CONV_TILE_STEM_B3 && c.wstemh) ||
+           (t >= CONV_TILE_B3R && t < CONV_TILE_B3R + 6 && c.wh2r);
+}
+
 static int assign_range_slots(accel_plan* p)
 {
-    std::map<int, int> slot_of;      // lowering id -> slot index
+    std::map<int, int>& slot_of = p->slot_of;      // lowering id -> slot index
     int n = 0;
-    std::vector<int> in_slot(p->ops.size(), -1);
+    p->in_slot.assign(p->ops.size(), -1);
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
-        if (op.kind != OP_CONV || !(op.conv.wh2r || op.conv.wubh || op.conv.wstemh)) continue;
-        if (op.rs_in < 0) in_slot[i] = n++;
+        if (op.kind != OP_CONV || !conv_has_h2_form(op.conv)) continue;
+        if (op.rs_in < 0) p->in_slot[i] = n++;
         else {
             auto it = slot_of.find(op.rs_in);
             if (it == slot_of.end()) it = slot_of.insert({op.rs_in, n++}).first;
-            in_slot[i] = it->second;
+            p->in_slot[i] = it->second;
         }
     }
     p->n_slots = n;
@@ -1171,27 +1184,39 @@ static int assign_range_slots(accel_plan* p)
     HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0] first offender's op index + 1, [1] the range it saw
     p->range_flag[0] = p->range_flag[1] = 0u;
     HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
+    for (size_t i = 0; i < p->ops.size(); ++i)
+        if (p->in_slot[i] >= 0) p->ops[i].conv.xr_slot = p->range + (size_t)p->in_slot[i] * RANGE_WORDS;
+    return 0;
+}
+
+static void resolve_range_flags(accel_plan* p, bool (*counts)(const ConvParams&))
+{
+    const int n = p->n_slots;
+    if (!n) return;
+    std::vector<char> used(n, 0);      // slots with a counting reader
+    for (size_t i = 0; i < p->ops.size(); ++i)
+        if (p->in_slot[i] >= 0 && counts(p->ops[i].conv)) used[p->in_slot[i]] = 1;
     auto addr = [&](int id) -> unsigned* {
-        auto it = id < 0 ? slot_of.end() : slot_of.find(id);
-        return it == slot_of.end() ? nullptr : p->range + (size_t)it->second * RANGE_WORDS;
+        auto it = id < 0 ? p->slot_of.end() : p->slot_of.find(id);
+        return (it == p->slot_of.end() || !used[it->second]) ? nullptr : p->range + (size_t)it->second * RANGE_WORDS;
     };
     std::vector<int> state(n, 0);      // 0: no writer yet, 1: every writer so far had the epilogue, 2: some writer had not
     std::vector<char> dirty(n, 0);     // partial words written since the last fold
     auto wrote = [&](int id, bool has_epilogue) {
-        auto it = id < 0 ? slot_of.end() : slot_of.find(id);
-        if (it == slot_of.end()) return;
+        auto it = id < 0 ? p->slot_of.end() : p->slot_of.find(id);
+        if (it == p->slot_of.end()) return;
         int& st = state[it->second];
         st = (has_epilogue && st != 2) ? 1 : 2;
         dirty[it->second] = 1;
     };
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
-        if (in_slot[i] >= 0) {      // reader first: an op never feeds itself
-            ConvParams& c = op.conv;
-            c.xr_slot = p->range + (size_t)in_slot[i] * RANGE_WORDS;
-            op.measure = state[in_slot[i]] != 1;
-            op.fold = op.measure || dirty[in_slot[i]];      // (a measuring pass raises partial words as well)
-            dirty[in_slot[i]] = 0;
+        op.measure = op.fold = false;
+        if (p->in_slot[i] >= 0 && counts(op.conv)) {      // reader first: an op never feeds itself
+            const int sl = p->in_slot[i];
+            op.measure = state[sl] != 1;
+            op.fold = op.measure || dirty[sl];      // (a measuring pass raises partial words as well)
+            dirty[sl] = 0;
         }
         switch (op.kind) {
         case OP_CONV:
@@ -1211,7 +1236,6 @@ static int assign_range_slots(accel_plan* p)
             break;
         }
     }
-    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1636,6 +1660,7 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         if (rc) return rc;
     }
     if (int rc = assign_range_slots(p)) return rc;
+    resolve_range_flags(p, conv_has_h2_form);      // for the tuning launches: every layer that could run the form counts
     if (p->ws_bytes) {
         HIP_TRY(hipMalloc((void**)&p->ws, p->ws_bytes));
         poison(p->ws, p->ws_bytes);
@@ -1685,6 +1710,7 @@ extern "C" int accel_plan_finalize(accel_plan* p)
         }
     }
     if (p->allow_tune) { int trc = autotune_plan(p); if (trc) return trc; HIP_TRY(hipDeviceSynchronize()); }
+    resolve_range_flags(p, conv_runs_h2);          // the geometries are final: only layers that run the fp16x2 form read a range
     if (use_graph) {
         hipStream_t st = p->m->ctx->stream;
         // one eager warm-up run: lazy module loading / function attributes must not happen under capture

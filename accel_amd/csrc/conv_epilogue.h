@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "conv_common.h"
 #include "range.h"
+#include <type_traits>
 
 // Shared tail of both conv kernels: split-K partial store or the fused epilogue
 // (scale/shift -> +residual -> activation -> store, optional dual output).
@@ -102,31 +103,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const bool note = p.yr != nullptr, note2 = p.y2 && p.y2r != nullptr;
 #endif
     unsigned rmax = 0u, rmax2 = 0u;
-    // per value: one fused multiply-add (none behind a residual: the accumulators already hold the pre-activation value) and one
-    // floating-point maximum -- |v| is v after a ReLU (a running maximum that starts at 0 IS the ReLU), max(v, -slope v) after a leaky
-    // one, the absolute-value source modifier otherwise.  (A NaN drops out of a floating-point maximum: it reaches the outputs
-    // through the matrix instructions as in fp32 arithmetic; an infinity stays visible and is reported by the fold.)
-    auto note_block = [&](int j) {
-        const bool ragged = rbase - 4 * (lane >> 5) + MI * 32 > p.M;      // wave-uniform: some rows of this wavefront lie past M
+    // Branch-free, whatever the layer's constants, and 1.5 vector instructions per value: v = acc * a + b (a = 1, b = 0 behind a
+    // residual: the accumulators already hold the pre-activation value; two values per packed multiply-add), a running MAXIMUM and a
+    // running MINIMUM of v (three-operand forms: two values per instruction each).  Everything else follows from the two extremes,
+    // once per column block: |act(v)| = max(v, c v) with c = 0 after a ReLU, -slope after a leaky one, -1 without an activation -- all
+    // <= 0, so its maximum is max(vmax, c vmin); the second output relu(act(v) scale2 + shift2) is a monotone map of v followed by a
+    // linear one, so its maximum sits at one of the two extremes.  (With the layer's constants tested inside the loop the pass compiled
+    // to a scalar branch tree per value: 8400 lines of ISA for the 128x128 tile, 2.5 ms of a 64 ms step; as a switch over
+    // straight-line variants it spilled 27 registers; per value with |act| taken inside 1.0 ms.  A NaN drops out of a floating-point
+    // maximum: it reaches the outputs through the matrix instructions as in fp32 arithmetic; an infinity stays visible and is
+    // reported by the fold.)
+    auto note_tile = [&]() __attribute__((always_inline)) {
+        const float c = p.act == 1 ? 0.f : p.act == 2 ? -p.slope : -1.f;
+        const float d = p.act == 1 ? 0.f : p.act == 2 ? p.slope : 1.f;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const f32x2 a2 = {p.res ? 1.f : sc[j], p.res ? 1.f : sc[j]}, b2 = {p.res ? 0.f : sf[j], p.res ? 0.f : sf[j]};
+            float vmax = -__builtin_inff(), vmin = __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 v = f32x2{acc[i][j][e], acc[i][j][e + 1]} * a2 + b2;
+                    vmax = fmaxf(fmaxf(vmax, v[0]), v[1]);
+                    vmin = fminf(fminf(vmin, v[0]), v[1]);
+                }
+            if (cok[j]) {
+                const float mj = fmaxf(fmaxf(vmax, c * vmin), 0.f);
+                const float r1 = fmaxf(vmax, d * vmax), r0 = fmaxf(vmin, d * vmin);      // act() at the two extremes
+                const float mj2 = fmaxf(fmaxf(r1 * sc2[j] + sf2[j], r0 * sc2[j] + sf2[j]), 0.f);
+                const unsigned bb = __builtin_bit_cast(unsigned, mj), b2_ = __builtin_bit_cast(unsigned, mj2);
+                rmax = bb > rmax ? bb : rmax; rmax2 = b2_ > rmax2 ? b2_ : rmax2;
+            }
+        }
+    };
+    auto note_general = [&](int j) __attribute__((always_inline)) {      // one column block (RES_PER_J tiles: behind that block's residual add)
+        const float c = p.act == 1 ? 0.f : p.act == 2 ? -p.slope : -1.f;
+        const float d = p.act == 1 ? 0.f : p.act == 2 ? p.slope : 1.f;
+        const float a = p.res ? 1.f : sc[j], b = p.res ? 0.f : sf[j];
         float mj = 0.f, mj2 = 0.f;
-        const float nslope = -p.slope;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = p.res ? acc[i][j][e] : acc[i][j][e] * sc[j] + sf[j];
-                if (ragged && rbase + i * 32 + (e & 3) + 8 * (e >> 2) >= p.M) v = 0.f;
-                if (p.act == 1) mj = fmaxf(mj, v);
-                else if (p.act == 2) mj = fmaxf(fmaxf(mj, v), v * nslope);
-                else mj = fmaxf(mj, __builtin_fabsf(v));
-                if (note2) {
-                    const float r = p.act == 1 ? fmaxf(v, 0.f) : p.act == 2 ? (v > 0.f ? v : v * p.slope) : v;
-                    mj2 = fmaxf(mj2, r * sc2[j] + sf2[j]);      // y2 = relu(.): the running maximum starts at 0
-                }
+                float v = acc[i][j][e] * a + b;
+                if (rbase + i * 32 + (e & 3) + 8 * (e >> 2) >= p.M) v = 0.f;
+                mj = fmaxf(mj, fmaxf(v, v * c));
+                mj2 = fmaxf(mj2, fmaxf(v, v * d) * sc2[j] + sf2[j]);
             }
         if (cok[j]) {
-            const unsigned b = __builtin_bit_cast(unsigned, mj), b2 = __builtin_bit_cast(unsigned, mj2);
-            rmax = b > rmax ? b : rmax; rmax2 = b2 > rmax2 ? b2 : rmax2;
+            const unsigned bb = __builtin_bit_cast(unsigned, mj), b2 = __builtin_bit_cast(unsigned, mj2);
+            rmax = bb > rmax ? bb : rmax; rmax2 = b2 > rmax2 ? b2 : rmax2;
         }
     };
 #pragma unroll
@@ -146,7 +173,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][e];
             }
-            if (note || note2) note_block(j);
+            if (note || note2) note_general(j);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -175,12 +202,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         }
     }
     // (behind the stores: the pass runs while they drain; the accumulators are still there, the values are recomputed from them)
+#ifdef RANGE_AB_NO_VALU      // timing experiment: the atomics without the pass over the accumulators
+    rmax = rmax2 = 0x3F800000u;
+#else
     if constexpr (!RES_PER_J) {
         if (note || note2) {
+            if (rbase - 4 * (lane >> 5) + MI * 32 > p.M) {      // wave-uniform: some rows of this wavefront lie past M -- value by value, masked
 #pragma unroll
-            for (int j = 0; j < NI; ++j) note_block(j);
+                for (int j = 0; j < NI; ++j) note_general(j);
+            } else note_tile();
         }
     }
+#endif
     // one atomic per wavefront into the partial word its index picks (1024 of them: no two wavefronts in flight meet)
     const unsigned key = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (note) range_note_wave(p.yr, rmax, key);

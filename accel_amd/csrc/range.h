@@ -27,14 +27,25 @@
 
 __device__ __forceinline__ unsigned range_abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
 
+// maximum over the wavefront (wave-uniform result; every lane of the wavefront must be active).
+// Six data-parallel-primitive moves on the vector ALU (quad permutes, row mirrors, the two row broadcasts of gfx9): the same reduction
+// through ds_bpermute (__shfl_xor) is a chain of six dependent LDS-pipeline round trips at the very end of a wavefront's life -- part
+// of the 3.2 ms per 65 ms step the first form of the conv epilogue's note pass cost (same-box A/B, scripts/ab_round.sh).
 __device__ __forceinline__ unsigned range_wave_max(unsigned u)
 {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)u, o);
-        u = t > u ? t : u;
-    }
-    return u;
+#define RANGE_DPP_MAX(ctrl, rmask)                                                                              \
+    do {                                                                                                        \
+        const unsigned t_ = (unsigned)__builtin_amdgcn_update_dpp((int)u, (int)u, ctrl, rmask, 0xF, false);     \
+        u = t_ > u ? t_ : u;                                                                                    \
+    } while (0)
+    RANGE_DPP_MAX(0xB1, 0xF);       // quad_perm [1,0,3,2]
+    RANGE_DPP_MAX(0x4E, 0xF);       // quad_perm [2,3,0,1]
+    RANGE_DPP_MAX(0x141, 0xF);      // row_half_mirror
+    RANGE_DPP_MAX(0x140, 0xF);      // row_mirror: every lane of a row of 16 holds the row's maximum
+    RANGE_DPP_MAX(0x142, 0xA);      // row_bcast15 into rows 1 and 3
+    RANGE_DPP_MAX(0x143, 0xC);      // row_bcast31 into rows 2 and 3: lane 63 holds the maximum of the wavefront
+#undef RANGE_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)u, 63);
 }
 
 // one atomic per wavefront; `key`: any index that differs between the wavefronts of a launch (spreads them over the partial words)
@@ -44,6 +55,10 @@ __device__ __forceinline__ void range_note_wave(unsigned* slot, unsigned m, unsi
     return;
 #endif
     m = range_wave_max(m);
+#ifdef RANGE_AB_NO_ATOMIC      // timing experiment: everything but the atomic
+    asm volatile("" :: "s"(m));
+    return;
+#endif
     if ((threadIdx.x & 63) == 0 && m) atomicMax(slot + RANGE_PART_OFF + (key & (RANGE_PART - 1)), m);
 }
 

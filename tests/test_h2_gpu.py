@@ -179,7 +179,7 @@ def test_the_producer_epilogue_raises_the_consumers_range(ctx, monkeypatch, grap
             mid = np.maximum(conv64(np.float32(f) * x, w1, 0), 0)
             ref = conv64(mid.astype(np.float32), w2, 0)
             s, src = plan.ranges()["b"]
-            assert src == 1 and plan.ranges()["a"][1] == 2             # b: from a's epilogue; a (reads an imported tensor): measured
+            assert src == 1 and plan.ranges()["a"] == (1.0, 0)         # b: from a's epilogue; a runs on the fp32 MFMA (geometry 0): it reads no range
             assert 2.0 ** 13 <= s * float(mid.max()) * (1 + 1e-6) and s * float(mid.max()) * (1 - 1e-6) < 2.0 ** 14, (f, s, mid.max())
             assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), f
             outs.setdefault(f, y)
