@@ -96,13 +96,6 @@ struct accel_model {
     // which buffer holds the current propagated feature: 0 = `feat`, 1 = `feat_b` (non-key graphs may be bound as a pair of
     // plans `cur` / `cur_b` that ping-pong between the two instead of copying the warped feature back; whoever wrote last)
     int feat_slot = 0;
-    // Score-resolution fusion (score_fuse_lowres_kernel: both upsampling filters the same for every class): the fused map lives in the
-    // persistent buffer `scores` ([images][H/16][W/16][ncls rounded up to 4] fp32) and `score_tpl` is the launch that expands such a map
-    // into logits + labels -- the plans' own last step, and what accel_expand_scores / accel_gather_scores run on a map that came from
-    // another GPU: the full-size logits are a pure function of a map 256x smaller.
-    ScoreTailParams score_tpl;
-    bool has_score_tpl = false;
-    int score_images = 0, score_zcs = 0;
     void source_written(const std::string& src) {
         ++generation[src];
         if (src == "feat") feat_slot = 0;
@@ -139,6 +132,7 @@ struct Op {
     ScoreTailParams tail;
     ScoreTailParams tail_lowres;   // set when the fusion can run at score resolution (uniform upsampling filter)
     float* tail_z = nullptr;
+    bool tail_copy = false;      // single-head tail: tail_z is a copy of the one score map (so that `scores` always holds what the logits are a function of)
     BufRef a, b, c, d;          // generic buffer slots
     const float* p0 = nullptr;  // generic device param slots
     const float* p1 = nullptr;
@@ -178,6 +172,13 @@ struct accel_plan {
     int split = 1;
     unsigned* range = nullptr;
     int n_slots = 0;
+    // Score-resolution tail (uniform upsampling filters): the plan leaves the map its logits are a pure function of -- the fused scores of
+    // the two heads (score_fuse_lowres_kernel) or the one head's scores -- in the model's persistent buffer `scores`
+    // ([images][H/16][W/16][ncls rounded up to 4] fp32) and `score_tpl` is the launch that expands such a map into logits + labels: the
+    // plan's own last step, and what accel_expand_scores / accel_gather_scores run on a map that came from another GPU.
+    ScoreTailParams score_tpl;
+    bool has_score_tpl = false;
+    int score_images = 0, score_zcs = 0;
     std::map<int, int> slot_of;      // lowering buffer id -> slot index
     std::vector<int> in_slot;        // per op: the slot a convolution with an fp16x2 form reads (-1: none)
     unsigned* range_flag = nullptr;       // host-mapped
@@ -869,6 +870,32 @@ static int input_slot(accel_plan* p, const BufRef& r, const float* const** out)
     return 0;
 }
 
+// the score-resolution map of a plan's tail lives in the model's persistent buffer `scores` (shared by the key and the non-key plan, like `logits`)
+static int scores_buffer(accel_plan* p, Op& op, const ScoreTailParams& q)
+{
+    const int zCs = roundup(q.ncls, 4);
+    const size_t zbytes = (size_t)op.a.N * q.Hs * q.Ws * zCs * sizeof(float);
+    DevBuf& zb = p->m->pbufs["scores"];
+    if (!zb.ptr) {
+        HIP_TRY(hipMalloc(&zb.ptr, zbytes));
+        zb.bytes = zbytes;
+        HIP_TRY(hipMemsetAsync(zb.ptr, 0, zbytes, p->m->ctx->stream));      // the pad channel stays zero
+    } else if (zb.bytes != zbytes) {
+        return fail(ACCEL_ERR_PLAN, "score_tail %s: the model's `scores` buffer has %zu bytes, this plan needs %zu", op.name.c_str(), zb.bytes, zbytes);
+    }
+    op.tail_z = static_cast<float*>(zb.ptr);
+    op.tail_lowres = q;
+    op.tail_lowres.left = op.tail_z; op.tail_lowres.lCs = zCs;
+    op.tail_lowres.right = nullptr; op.tail_lowres.wr = nullptr;
+    op.tail_lowres.uniform_w = 1;
+    p->score_tpl = op.tail_lowres;
+    p->score_tpl.cw = nullptr;
+    p->has_score_tpl = true;
+    p->score_images = op.a.N;
+    p->score_zcs = zCs;
+    return 0;
+}
+
 static int finalize_op(accel_plan* p, Op& op)
 {
     const KV& kv = op.kv;
@@ -996,27 +1023,13 @@ static int finalize_op(accel_plan* p, Op& op)
                 uniform = !memcmp(hl->data.data(), hl->data.data() + (size_t)c * 1024, 4096) &&
                           !memcmp(hl->data.data(), hr->data.data() + (size_t)c * 1024, 4096);
             if (uniform) {
-                const int zCs = roundup(q.ncls, 4);
-                // the fused map is the model's persistent buffer `scores` (shared by the key and the non-key plan, like `logits`)
-                const size_t zbytes = (size_t)op.a.N * q.Hs * q.Ws * zCs * sizeof(float);
-                DevBuf& zb = p->m->pbufs["scores"];
-                if (!zb.ptr) {
-                    HIP_TRY(hipMalloc(&zb.ptr, zbytes));
-                    zb.bytes = zbytes;
-                    HIP_TRY(hipMemsetAsync(zb.ptr, 0, zbytes, p->m->ctx->stream));      // the pad channel stays zero
-                } else if (zb.bytes != zbytes) {
-                    return fail(ACCEL_ERR_PLAN, "score_tail %s: the model's `scores` buffer has %zu bytes, this plan needs %zu", op.name.c_str(), zb.bytes, zbytes);
-                }
-                op.tail_z = static_cast<float*>(zb.ptr);
-                op.tail_lowres = q;
-                op.tail_lowres.left = op.tail_z; op.tail_lowres.lCs = zCs;
-                op.tail_lowres.right = nullptr; op.tail_lowres.wr = nullptr; op.tail_lowres.cw = nullptr;   // cb stays: bias after upsampling
-                op.tail_lowres.uniform_w = 1;
-                p->m->score_tpl = op.tail_lowres;
-                p->m->has_score_tpl = true;
-                p->m->score_images = op.a.N;
-                p->m->score_zcs = zCs;
+                if ((rc = scores_buffer(p, op, q))) return rc;
+                op.tail_lowres.cw = nullptr;      // cb stays: the bias is added after upsampling
             }
+        }
+        if (!op.b.set && q.uniform_w) {      // single head with one filter for every class: its score map goes through `scores` as well (a copy)
+            if ((rc = scores_buffer(p, op, q))) return rc;
+            op.tail_copy = true;
         }
         return 0;
     }
@@ -1063,7 +1076,9 @@ static int launch_op(accel_plan* p, Op& op)
     }
     case OP_SCORE_TAIL: {
         const int N = op.a.N;
-        if (op.tail_z)     // low-resolution fusion is pixel-wise: one launch over all images
+        if (op.tail_z && op.tail_copy)
+            e = launch_copy_view(op.tail.left, op.tail.lCs, op.tail_z, op.tail_lowres.lCs, op.tail.ncls, N * op.tail.Hs * op.tail.Ws, st, nullptr);
+        else if (op.tail_z)     // low-resolution fusion is pixel-wise: one launch over all images
             e = launch_score_fuse_lowres(op.tail.left, op.tail.lCs, op.tail.right, op.tail.rCs, op.tail.cw, op.tail_z,
                                          op.tail_lowres.lCs, op.tail.ncls, N * op.tail.Hs * op.tail.Ws, st);
         if (e == hipSuccess) {
@@ -2538,41 +2553,42 @@ extern "C" int accel_gather_frames(accel_comm* c, const void* sendbuf, size_t se
 // map the plan leaves in `scores` (20 x H/16 x W/16 floats: 0.66 MB).  Peers send that map; the root expands every block with the very
 // launch its own plans end with (score_tail_uniform_kernel over the model's filter and bias), so the expanded logits are bit-identical
 // to what the peer computed.  Round 4 measured the logits gather at 93 GB/s per peer link against ~77 sustainable: link-bound.
-extern "C" int accel_expand_scores(accel_model* m, const void* scores_dev, int n_images, float* logits_dev, unsigned char* labels_dev, accel_comm* on_comm_stream_of)
+extern "C" int accel_expand_scores(accel_plan* p, const void* scores_dev, int n_images, float* logits_dev, unsigned char* labels_dev, accel_comm* on_comm_stream_of)
 {
-    if (!m || !scores_dev || !logits_dev || !labels_dev || n_images < 1) return fail(ACCEL_ERR_ARG, "accel_expand_scores: bad argument");
-    if (!m->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_expand_scores: the model fuses its scores at full resolution (no `scores` buffer: the upsampling "
-                                                       "filters are not uniform, or no plan with a two-head score tail is finalized)");
-    HIP_TRY(hipSetDevice(m->ctx->device));
-    ScoreTailParams q = m->score_tpl;
+    if (!p || !p->finalized || !scores_dev || !logits_dev || !labels_dev || n_images < 1) return fail(ACCEL_ERR_ARG, "accel_expand_scores: bad argument");
+    if (!p->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_expand_scores: plan '%s' forms its logits at full resolution (no `scores` map: the upsampling "
+                                                       "filters are not uniform, or the plan has no score tail)", p->role.c_str());
+    HIP_TRY(hipSetDevice(p->m->ctx->device));
+    ScoreTailParams q = p->score_tpl;
     q.left = static_cast<const float*>(scores_dev);
     q.logits = logits_dev;
     q.labels = labels_dev;
     q.N = n_images;
-    const hipError_t e = launch_score_tail(q, on_comm_stream_of ? on_comm_stream_of->stream : m->ctx->stream);
+    const hipError_t e = launch_score_tail(q, on_comm_stream_of ? on_comm_stream_of->stream : p->m->ctx->stream);
     if (e != hipSuccess) return fail(ACCEL_ERR_HIP, "accel_expand_scores: launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 
-// Every rank contributes the `scores` buffer of `m` (own_images of the slot_images a slot holds: only the root may contribute fewer);
-// the root receives the maps into recv_scores ([nranks][slot_images] maps) and expands rank r's block into logits_out / labels_out at
-// image offset r * slot_images, on the communication stream right behind the receives -- no host synchronisation anywhere; the results
-// are valid after accel_comm_sync.  Peers pass NULL for the three root-side buffers.
-extern "C" int accel_gather_scores(accel_comm* c, accel_model* m, int own_images, int slot_images, void* recv_scores, float* logits_out,
+// Every rank contributes the `scores` buffer its plan `p` has just filled (own_images of the slot_images a slot holds: only the root may
+// contribute fewer; every rank passes the plan of the SAME role -- key and non-key frames expand differently: one head without a bias
+// against the fused heads with the correction bias); the root receives the maps into recv_scores ([nranks][slot_images] maps) and
+// expands rank r's block into logits_out / labels_out at image offset r * slot_images, on the communication stream right behind the
+// receives -- no host synchronisation anywhere; the results are valid after accel_comm_sync.  Peers pass NULL for the three root-side buffers.
+extern "C" int accel_gather_scores(accel_comm* c, accel_plan* p, int own_images, int slot_images, void* recv_scores, float* logits_out,
                                    unsigned char* labels_out, int root)
 {
-    if (!c || !m || own_images < 1 || slot_images < own_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: bad argument");
-    if (!m->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_gather_scores: the model has no `scores` buffer (see accel_expand_scores)");
-    if (own_images > m->score_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: %d images asked for, the model's plans produce %d", own_images, m->score_images);
+    if (!c || !p || !p->finalized || own_images < 1 || slot_images < own_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: bad argument");
+    if (!p->has_score_tpl) return fail(ACCEL_ERR_PLAN, "accel_gather_scores: plan '%s' has no `scores` map (see accel_expand_scores)", p->role.c_str());
+    if (own_images > p->score_images) return fail(ACCEL_ERR_ARG, "accel_gather_scores: %d images asked for, the plan produces %d", own_images, p->score_images);
     if (c->rank == root && (!recv_scores || !logits_out || !labels_out)) return fail(ACCEL_ERR_ARG, "accel_gather_scores: the root needs its three buffers");
-    const ScoreTailParams& t = m->score_tpl;
-    const size_t map_bytes = (size_t)t.Hs * t.Ws * m->score_zcs * sizeof(float);
-    int rc = accel_gather_frames(c, m->pbufs["scores"].ptr, (size_t)own_images * map_bytes, recv_scores, (size_t)slot_images * map_bytes, root);
+    const ScoreTailParams& t = p->score_tpl;
+    const size_t map_bytes = (size_t)t.Hs * t.Ws * p->score_zcs * sizeof(float);
+    int rc = accel_gather_frames(c, p->m->pbufs["scores"].ptr, (size_t)own_images * map_bytes, recv_scores, (size_t)slot_images * map_bytes, root);
     if (rc || c->rank != root) return rc;
     const size_t img_logits = (size_t)t.ncls * t.H * t.W, img_labels = (size_t)t.H * t.W;
     for (int r = 0; r < c->nranks; ++r) {
         const int n = r == root ? own_images : slot_images;
-        rc = accel_expand_scores(m, static_cast<const char*>(recv_scores) + (size_t)r * slot_images * map_bytes, n,
+        rc = accel_expand_scores(p, static_cast<const char*>(recv_scores) + (size_t)r * slot_images * map_bytes, n,
                                  logits_out + (size_t)r * slot_images * img_logits, labels_out + (size_t)r * slot_images * img_labels, c);
         if (rc) return rc;
     }

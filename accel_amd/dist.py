@@ -276,15 +276,17 @@ class ScoreGather(object):
         self.work = [None, None]
         self.logits = self.labels = None
 
-    def submit(self):
+    def submit(self, plan=None):
+        """plan: the runtime.Plan this rank has just run (GPU path; every rank the plan of the same role -- a key plan's map expands
+        without the correction bias, a non-key plan's with it)"""
         s = self.n & 1
         if self.comm is not None:
             r = self.rank == 0
-            self.comm.gather_scores(self.model, self.own, self.B, self.recv[s].data_ptr() if r else None,
+            self.comm.gather_scores(plan, self.own, self.B, self.recv[s].data_ptr() if r else None,
                                     self.logits.data_ptr() if r else None, self.labels.data_ptr() if r else None, 0)
             for k in range(self.emulate if r else 0):
                 at = (self.world + k) * self.B
-                self.model.expand_scores(self.recv[s].data_ptr(), self.B, self.logits[at].data_ptr(), self.labels[at].data_ptr(), comm=self.comm)
+                plan.expand_scores(self.recv[s].data_ptr(), self.B, self.logits[at].data_ptr(), self.labels[at].data_ptr(), comm=self.comm)
         else:
             if self.work[s] is not None:
                 self.work[s].wait()

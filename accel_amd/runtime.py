@@ -317,10 +317,11 @@ class Comm(object):
             check(lib().accel_gather_frames(self.handle, ctypes.c_void_p(send_ptr), int(send_bytes),
                                             ctypes.c_void_p(recv_ptr) if recv_ptr else None, int(nbytes), int(root)))
 
-    def gather_scores(self, model, own_images, slot_images, recv_scores=None, logits_out=None, labels_out=None, root=0):
-        """accel_gather_scores: every rank's fused score maps to the root, expanded there into logits + labels (device pointers; None on peers)"""
+    def gather_scores(self, plan, own_images, slot_images, recv_scores=None, logits_out=None, labels_out=None, root=0):
+        """accel_gather_scores: the score maps plan `plan` has just left in `scores`, from every rank to the root, expanded there into
+        logits + labels (device pointers; None on peers)"""
         vp = lambda p: ctypes.c_void_p(p) if p else None
-        check(lib().accel_gather_scores(self.handle, model.handle, int(own_images), int(slot_images), vp(recv_scores), vp(logits_out), vp(labels_out), int(root)))
+        check(lib().accel_gather_scores(self.handle, plan.handle, int(own_images), int(slot_images), vp(recv_scores), vp(logits_out), vp(labels_out), int(root)))
 
     def sync(self):
         check(lib().accel_comm_sync(self.handle))
@@ -370,6 +371,11 @@ class Plan(object):
                 check(lib().accel_plan_op_info(self.handle, i, kind, name, None, None))
                 out[name.value.decode()] = (s.value, int(src.value))
         return out
+
+    def expand_scores(self, scores_ptr, n_images, logits_ptr, labels_ptr, comm=None):
+        """accel_expand_scores: logits + labels of n_images score maps (device pointers) by this plan's own last launch"""
+        check(lib().accel_expand_scores(self.handle, ctypes.c_void_p(scores_ptr), int(n_images), ctypes.c_void_p(logits_ptr), ctypes.c_void_p(labels_ptr),
+                                        comm.handle if comm is not None else None))
 
     def run_serial(self):
         """diagnostics: every op in list order on the context stream (no graph replay), then a host wait"""
@@ -437,11 +443,6 @@ class Model(object):
     def read_device(self, buf, dev_ptr, nbytes):
         """enqueue a D2D copy of a persistent buffer into caller-owned HBM (no host sync)"""
         check(lib().accel_model_read(self.handle, buf.encode(), ctypes.c_void_p(dev_ptr), nbytes, 1))
-
-    def expand_scores(self, scores_ptr, n_images, logits_ptr, labels_ptr, comm=None):
-        """accel_expand_scores: logits + labels of n_images fused score maps (device pointers) by the model's own last launch"""
-        check(lib().accel_expand_scores(self.handle, ctypes.c_void_p(scores_ptr), int(n_images), ctypes.c_void_p(logits_ptr), ctypes.c_void_p(labels_ptr),
-                                        comm.handle if comm is not None else None))
 
     def has_buffer(self, buf):
         ptr, n = ctypes.c_void_p(), ctypes.c_size_t()

@@ -299,6 +299,10 @@ class Workload(object):
         self.gather = None
         self.bind_inputs = os.environ.get("ACCEL_BENCH_BIND_INPUTS") == "1"
 
+    @property
+    def scores_gather(self):
+        return type(self.gather).__name__ == "ScoreGather"
+
     def step(self):
         """one clip per lane: key frame + (interval - 1) non-key frames, inputs and outputs in HBM"""
         m = self.model
@@ -310,12 +314,13 @@ class Workload(object):
         for t in range(self.interval):
             put("data", self.dev_frames[t].data_ptr(), self.nbytes)
             if t == 0:
-                self.key.run()
+                plan = self.key
             else:
                 put("data_key", self.dev_frames[t - 1].data_ptr(), self.nbytes)
-                (self.cur if t % 2 else self.cur_b).run()      # frame 1 reads the key plan's `feat`, frame 2 `feat_b`, ...
+                plan = self.cur if t % 2 else self.cur_b      # frame 1 reads the key plan's `feat`, frame 2 `feat_b`, ...
+            plan.run()
             if self.gather is not None:
-                self.gather.submit()
+                self.gather.submit(plan) if self.scores_gather else self.gather.submit()
 
     def sync(self):
         if self.gather is not None:

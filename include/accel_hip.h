@@ -238,16 +238,18 @@ int accel_gather_frames(accel_comm* comm, const void* sendbuf, size_t send_bytes
  * class (the reference freezes them at the bilinear initialisation, accel_18.py:153) the plans fuse the two heads at score resolution
  * and leave the fused map in the model's persistent buffer `scores` ([images][H/16][W/16][ncls rounded up to 4] fp32, 0.66 MB per
  * 1024x2048 frame); the fp32 logits (159 MB) are a pure function of it.
- *   accel_expand_scores   logits + labels of n_images maps at scores_dev (HBM, layout of `scores`) by the very launch the model's own
- *                         plans end with: bit-identical to the logits the producing GPU computed.  Enqueued on the model's compute
+ *   (A key plan's tail has ONE head and no correction bias, a non-key plan's the fused two: the expansion belongs to a PLAN.  Both leave
+ *   their map in the same `scores` buffer; every rank passes the plan it has just run -- the ranks of a job run the same schedule.)
+ *   accel_expand_scores   logits + labels of n_images maps at scores_dev (HBM, layout of `scores`) by the very launch plan p ends
+ *                         with: bit-identical to the logits the producing GPU computed.  Enqueued on the model's compute
  *                         stream, or on a communicator's communication stream (on_comm_stream_of != NULL).
  *   accel_gather_scores   accel_gather_frames of the `scores` buffer (own_images of the slot_images a rank's slot holds; only the
  *                         root may contribute fewer) followed, on the root and on the communication stream, by the expansion of every
  *                         rank's block into logits_out / labels_out ([nranks * slot_images] images); valid after accel_comm_sync.
  * ACCEL_ERR_PLAN if the model has no `scores` buffer (filters not uniform): gather the logits then.  (Reference pattern: per-device
  * results merged on the host, dff_rfcn/function/test_rcnn.py:62-82.) */
-int accel_expand_scores(accel_model* m, const void* scores_dev, int n_images, float* logits_dev, unsigned char* labels_dev, accel_comm* on_comm_stream_of);
-int accel_gather_scores(accel_comm* comm, accel_model* m, int own_images, int slot_images, void* recv_scores_or_null, float* logits_out_or_null,
+int accel_expand_scores(accel_plan* p, const void* scores_dev, int n_images, float* logits_dev, unsigned char* labels_dev, accel_comm* on_comm_stream_of);
+int accel_gather_scores(accel_comm* comm, accel_plan* p, int own_images, int slot_images, void* recv_scores_or_null, float* logits_out_or_null,
                         unsigned char* labels_out_or_null, int root);
 int accel_comm_sync(accel_comm* comm);
 

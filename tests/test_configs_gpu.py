@@ -357,7 +357,7 @@ def test_config4_score_gather_expands_to_the_peers_own_logits(demo_cfg, sendrecv
         assert g.transport == "cabi" and g.recv[0].shape == (1, 1, H // 16, W // 16, 20)
         for t in range(4):
             lg, lab = r.step(t, data[t], interval)
-            g.submit()
+            g.submit((r.key_predictor if t % interval == 0 else r.cur_predictor).plan_for(H, W, 1)[0])
             g.drain()
             want, wlab = lg.asnumpy(), np.uint8(lab.asnumpy())
             got, glab = g.logits.cpu().numpy(), g.labels.cpu().numpy()
