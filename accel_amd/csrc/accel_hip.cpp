@@ -1236,9 +1236,14 @@ static void resolve_range_flags(accel_plan* p, bool (*counts)(const ConvParams&)
         switch (op.kind) {
         case OP_CONV:
             // (half outputs: the lowering keeps a buffer half only if every reader is an f16-mode convolution -- none has an fp16x2 form)
-            op.conv.yr = op.conv.y_half ? nullptr : addr(op.rs_out);
-            op.conv.y2r = addr(op.rs_out2);
-            wrote(op.rs_out, !op.conv.y_half); wrote(op.rs_out2, true);
+            // and the f16-mode kernels of conv_b3d.hip have no range epilogue: a reader of their output measures its view)
+            {
+                const int t = op.conv.force_tile;
+                const bool ep = !op.conv.y_half && !(t >= CONV_TILE_B3D && t < CONV_TILE_B3D + CONV_TILE_B3D_N) && !(op.conv.x_half || op.conv.res_half);
+                op.conv.yr = ep ? addr(op.rs_out) : nullptr;
+                op.conv.y2r = ep ? addr(op.rs_out2) : nullptr;
+                wrote(op.rs_out, ep); wrote(op.rs_out2, ep);
+            }
             break;
         case OP_POOL: op.pool.yr = addr(op.rs_out); wrote(op.rs_out, true); break;
         case OP_DCN_COLS: op.dcn.yr = op.dcn.col_half ? nullptr : addr(op.rs_out); wrote(op.rs_out, !op.dcn.col_half); break;

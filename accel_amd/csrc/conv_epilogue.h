@@ -97,10 +97,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // version: headline 626 -> 571 frames/s).  Rows past M do not count (masked where the tile is ragged), channels past Cout_store
     // neither; rows a cropped deconvolution drops (odd sizes) do: they are outputs of the same layer, the slot stays a bound and a
     // function of the run's data.
+    // (RES_PER_J tiles -- the f16-mode kernels of conv_b3d.hip, 128-256 accumulator registers per lane -- carry no range epilogue at
+    // all: with it they went from 163 to 256 registers and spilled 200; the library knows, and a reader of their output measures its
+    // view itself: accel_hip.cpp resolve_range_flags)
 #ifdef RANGE_AB_NO_NOTE
     const bool note = false, note2 = false;
 #else
-    const bool note = p.yr != nullptr, note2 = p.y2 && p.y2r != nullptr;
+    const bool note = !RES_PER_J && p.yr != nullptr, note2 = !RES_PER_J && p.y2 && p.y2r != nullptr;
 #endif
     unsigned rmax = 0u, rmax2 = 0u;
     // Branch-free, whatever the layer's constants, and 1.5 vector instructions per value: v = acc * a + b (a = 1, b = 0 behind a
@@ -173,7 +176,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = acc[i][j][e] * sc[j] + sf[j] + rv[i][e];
             }
-            if (note || note2) note_general(j);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -230,8 +232,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // the odd lane the pair of the second row as ONE dword -- half as many store instructions as a 2-byte store per value would need,
 // each covering whole 64-byte runs; the half residual is fetched the same way (one dword per lane and row pair) and exchanged back.
 // No dual output (the plan keeps such layers in fp32).
-// Half outputs carry no range slot (the lowering keeps a buffer half only when every reader is an f16-mode convolution, which has no
-// fp16x2 form); an fp32 output written from here (half residual) notes its range like conv_epilogue.
+// No range epilogue (range.h): half outputs have no fp16x2-form reader, and a reader of an fp32 output written from here measures its view
+// itself (the library treats the conv_b3d.hip geometries as writers without the epilogue).
 template <int MI, int NI, int WGN>
 __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
                                                 int lane, int py, int px, int HoWo)
@@ -240,8 +242,7 @@ __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&ac
         conv_epilogue<MI, NI, WGN, true>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo);
         return;
     }
-    const bool note = p.yr != nullptr && !p.y_half;
-    unsigned rmax = 0u;
+
     const int rbase = m0 + wm * MI * 32 + 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res : p.y, p.res ? p.res_bytes : 0u);
@@ -314,10 +315,8 @@ __device__ __forceinline__ void conv_epilogue_h(const ConvParams& p, f32x16 (&ac
                 for (int e = 0; e < 16; ++e) {
                     const unsigned px_ = pixel_of(rbase + i * 32 + (e & 3) + 8 * (e >> 2));
                     buf_store1(yr, (cok && px_ != OOB) ? (px_ * p.yCs + co) * 4u : OOB, v[e]);
-                    if (note) { const unsigned b = (cok && px_ != OOB) ? range_abs_bits(v[e]) : 0u; rmax = b > rmax ? b : rmax; }
                 }
             }
         }
     }
-    if (note) range_note_wave(p.yr, rmax, (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 7u * blockIdx.y);
 }
