@@ -2505,10 +2505,10 @@ extern "C" int accel_gather_logits(accel_comm* c, const void* sendbuf, void* rec
 // receives everybody else's frames): its own block is a device copy of send_bytes, the rest of its slot is left untouched.
 extern "C" int accel_gather_frames(accel_comm* c, const void* sendbuf, size_t send_bytes, void* recvbuf_or_null, size_t bytes, int root)
 {
-    if (!c || !sendbuf || !bytes || !send_bytes || send_bytes > bytes) return fail(ACCEL_ERR_ARG, "accel_gather_logits: bad argument");
+    if (!c || !sendbuf || !bytes || !send_bytes || send_bytes > bytes) return fail(ACCEL_ERR_ARG, "accel_gather_frames: bad argument");
     if (c->rank != root && send_bytes != bytes) return fail(ACCEL_ERR_ARG, "accel_gather_frames: only the root may send less than a full slot");
-    if (root < 0 || root >= c->nranks) return fail(ACCEL_ERR_ARG, "accel_gather_logits: root %d out of range", root);
-    if (c->rank == root && !recvbuf_or_null) return fail(ACCEL_ERR_ARG, "accel_gather_logits: the root needs a receive buffer");
+    if (root < 0 || root >= c->nranks) return fail(ACCEL_ERR_ARG, "accel_gather_frames: root %d out of range", root);
+    if (c->rank == root && !recvbuf_or_null) return fail(ACCEL_ERR_ARG, "accel_gather_frames: the root needs a receive buffer");
     HIP_TRY(hipSetDevice(c->ctx->device));
     const int s = (int)(c->n & 1);
     hipStream_t compute = c->ctx->stream;

@@ -755,14 +755,28 @@ def _run(a):
             rf = w5.conv_roofline("f16")
             sec["accel50_f16_2048x4096_kf10"] = {
                 "value": round(2 * 10 / el, 2), "unit": "frames/s", "clips_per_call": 1,
-                "what": "BASELINE config 5 on one GPU: Accel-50, fp16-MFMA convolutions with fp32 storage / accumulation (REDUCED precision: "
-                        "error against the fp32 oracle 4-5 % of the logit range at the worst pixel, tests/test_f16_gpu.py), 2048x4096, kf=10",
+                "what": "BASELINE config 5 on one GPU: Accel-50, fp16-MFMA convolutions (operands rounded to half, ONE product, fp32 accumulation) with "
+                        "HALF activation storage between half-capable layers (REDUCED precision: error against the fp32 oracle 4-5 % of the logit range "
+                        "at the worst pixel, tests/test_f16_gpu.py, tests/test_f16_storage_gpu.py), 2048x4096, kf=10",
                 "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_fp16_peak": rf["all_conv"]["frac"]}
             w5.close()
         except Exception as e:
             sec["accel50_f16_2048x4096_kf10"] = {"error": repr(e)}
         finally:
             os.environ["ACCEL_CONV_DTYPE"] = a.dtype
+        # ... and the same model, size and schedule in the DEFAULT arithmetic (fp32-class accuracy, fp16x2 form): what the reduced precision buys
+        try:
+            w6 = Workload("50", 1, 2048, 4096, 10, local_rank, rank, config)
+            el = w6.timed(2, 1)
+            rf = w6.conv_roofline(a.dtype)
+            sec["accel50_2048x4096_kf10_fp16x2"] = {
+                "value": round(2 * 10 / el, 2), "unit": "frames/s", "clips_per_call": 1,
+                "what": "Accel-50, 2048x4096, kf=10, one clip, in the default arithmetic of the headline (fp32 storage and accuracy, fp16x2 form of the "
+                        "matrix-core layers): the line config 5's f16 mode has to be read against",
+                "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_peak": rf["all_conv"]["frac"]}
+            w6.close()
+        except Exception as e:
+            sec["accel50_2048x4096_kf10_fp16x2"] = {"error": repr(e)}
         out["secondary"] = sec
     else:
         wl.close()
