@@ -72,7 +72,7 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
     check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
 
 
-@pytest.mark.parametrize("geometry", [41, 42, 43])
+@pytest.mark.parametrize("geometry", [pytest.param(41, marks=pytest.mark.gpu_extra), 42, 43])
 def test_winograd_bf16_geometry_on_every_eligible_layer_vs_oracle(demo_cfg, monkeypatch, tmp_path, geometry):
     """The launch-geometry table decides per layer; this test does not depend on what it decided: EVERY layer that can take
     the Winograd-on-bf16 geometry 41 / 42 / 43 (every 3x3 / stride 1 layer of the two ResNet branches with channels in
@@ -284,7 +284,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("transport", ["cabi", "cabi-sendrecv", "torch"])
+@pytest.mark.parametrize("transport", ["cabi", "cabi-sendrecv", pytest.param("torch", marks=pytest.mark.gpu_extra)])
 def test_config4_rccl_gather_on_one_gpu(demo_cfg, transport, monkeypatch):
     """FrameGather over RCCL with a world of one rank -- through accel_gather_logits of the C ABI ("cabi": libaccel_hip
     + librccl, the default) and through torch.distributed ("torch", the fallback): the gathered tensor of every frame

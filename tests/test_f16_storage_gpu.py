@@ -141,7 +141,7 @@ def half_layers(version, H, W, cfg):
     return names
 
 
-@pytest.mark.parametrize("version", ["50", "101"])
+@pytest.mark.parametrize("version", ["50", pytest.param("101", marks=pytest.mark.gpu_extra)])
 def test_clip_with_half_storage_against_its_specification_512x1024(demo_cfg, monkeypatch, version):
     """Whole clip, Accel-50 (config 5's model) and Accel-101, key + non-key frame at 512x1024 in f16 mode with half storage against
     the oracle on half-rounded operands AND half-rounded stored tensors (STORE_F16 = the layers the lowering stores as half).  As

@@ -30,7 +30,7 @@ def _check(outs, ref, tag):
     check_against_oracle(outs, ref, tag)
 
 
-@pytest.mark.parametrize("version", ["18", "34"])
+@pytest.mark.parametrize("version", ["18", pytest.param("34", marks=pytest.mark.gpu_extra)])
 def test_clip_parity_without_linear_fold(demo_cfg, version, monkeypatch):
     """ACCEL_FOLD_LINEAR=0 runs `feat_upsampling` and `fc6` as the reference's two separate layers; the default
     (composed deconvolution) is what every other test in this file exercises.  Both must match the oracle."""
@@ -51,7 +51,7 @@ def test_clip_parity_without_linear_fold(demo_cfg, version, monkeypatch):
     _check(runner_outs, ref, "accel-%s unfolded" % version)
 
 
-@pytest.mark.parametrize("version", ["18", "101"])
+@pytest.mark.parametrize("version", ["18", pytest.param("101", marks=pytest.mark.gpu_extra)])
 def test_clip_parity_dcn_stress_offsets_x20(demo_cfg, version):
     """SURVEY.md 8d "stress set x20": the deformable layers' offset convolutions drawn 20x wider (offsets of 15-30 px, most
     taps of the outer rings land outside the image), whole clip against the oracle.  The operator is discontinuous at the
@@ -215,7 +215,7 @@ def test_deeplab_frame_by_frame_baseline(demo_cfg):
     np.testing.assert_array_equal(lab[0][safe], np.argmax(ref, axis=1)[0][safe])
 
 
-@pytest.mark.parametrize("H,W", [(256, 384), (384, 128), (160, 288), (96, 224)])
+@pytest.mark.parametrize("H,W", [(256, 384), pytest.param(384, 128, marks=pytest.mark.gpu_extra), pytest.param(160, 288, marks=pytest.mark.gpu_extra), (96, 224)])
 def test_other_aspect_ratios(demo_cfg, H, W):
     """sizes other than 1:2, and sizes that are multiples of 32 but not of 128 (odd FlowNet encoder sizes: the
     decoder's Crop(offset 1) then keeps 2h-1 rows of a deconvolution, resnet_v1_101_flownet_deeplab.py:1776-1801);
@@ -234,7 +234,7 @@ def test_other_aspect_ratios(demo_cfg, H, W):
     _check(outs, G.run_clip(P, "18", _oracle_frames(frames, demo_cfg), 2), "accel-18 %dx%d" % (H, W))
 
 
-@pytest.mark.parametrize("version,H,W", [("18", 144, 272), ("34", 208, 176), ("101", 144, 272), ("18", 1040, 2064)])
+@pytest.mark.parametrize("version,H,W", [("18", 144, 272), ("34", 208, 176), ("101", 144, 272), pytest.param("18", 1040, 2064, marks=pytest.mark.gpu_extra)])
 def test_sizes_that_are_multiples_of_16_only(demo_cfg, version, H, W):
     """The reference binds any size its own shape inference accepts, i.e. any multiple of 16 (the head upsamples H/16 x W/16
     by exactly 16).  At multiples of 16 that are not multiples of 32 the stride-32 correction branch of Accel-18 / 34,
@@ -457,7 +457,7 @@ def test_stale_feature_handle_is_never_read_silently(demo_cfg):
         tester.release_models()
 
 
-@pytest.mark.parametrize("version", ["18", "101"])
+@pytest.mark.parametrize("version", ["18", pytest.param("101", marks=pytest.mark.gpu_extra)])
 def test_batched_clips_match_single_clip_runs(demo_cfg, version):
     """Throughput mode: every call runs one frame of each of B independent clips (arrays with a leading batch of B).
     Image b of the batched run must reproduce the batch-1 run of clip b (same kernels, other tile choices: compared
