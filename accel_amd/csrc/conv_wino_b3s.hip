@@ -184,9 +184,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][jj][e] = 0.f;
     auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[NPW]) {
-#ifdef WS_SETPRIO      // experiment (scripts/ab_variants.sh): the wavefront that has matrix instructions to issue goes first on its SIMD
-        __builtin_amdgcn_s_setprio(WS_SETPRIO);
-#endif
         if constexpr (H2) {      // the two cross terms, then hi * hi
             constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
@@ -221,11 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
     read_raw(0, P0);
     split_raw(aA);
 
-#ifdef WS_SETPRIO
-#define WS_FENCE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); } while (0)
-#else
 #define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 #define WS_INTERLEAVE(nv)                                                                             \
     do {                                                                                              \
         _Pragma("unroll") for (int g_ = 0; g_ < (H2 ? 3 : 6); ++g_) {                                 \
