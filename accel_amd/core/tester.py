@@ -152,8 +152,8 @@ class Predictor(object):
             model._params_token = token
         self._model = model
         # non-key graphs bind as a PAIR of plans that ping-pong the propagated feature between two buffer pairs (no
-        # copy-back after the warp, lower.Lowering.__init__); ACCEL_FEAT_PINGPONG=0 keeps the single plan with copies
-        pingpong = not self._is_key and not self._is_train and os.environ.get("ACCEL_FEAT_PINGPONG", "1") != "0"
+        # copy-back after the warp, lower.Lowering.__init__)
+        pingpong = not self._is_key and not self._is_train
         # every plan is lowered for ONE stream (a two-stream lowering existed until round 3 and was removed: DESIGN.md 7)
         fold = os.environ.get("ACCEL_FOLD_LINEAR", "1") != "0"
         kw = dict(conv_dtype=os.environ.get("ACCEL_CONV_DTYPE", "f32"), fold_linear=fold)

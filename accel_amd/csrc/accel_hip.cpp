@@ -194,6 +194,23 @@ struct accel_plan {
 // ---------------------------------------------------------------------------
 static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
+// ACCEL_WITHHOLD="winograd,ws1x1,...": kernel families a plan does NOT offer to its tuner (A/B runs and diagnostics; a geometry a
+// conv forces with tile= is packed regardless).  Families: split (every bf16x3 / fp16x2 geometry: the fp32 MFMA kernels remain),
+// b3r (conv_b3r.hip), winograd, winograd_split (41-43), stem, stem_split (51), ws1x1, deep (the deep-prefetch tiles 31-35).
+static bool withheld(const char* family)
+{
+    const char* e = getenv("ACCEL_WITHHOLD");
+    if (!e) return false;
+    const size_t n = strlen(family);
+    for (const char* q = e; *q;) {
+        const char* c = strchr(q, ',');
+        const size_t len = c ? (size_t)(c - q) : strlen(q);
+        if (len == n && !strncmp(q, family, n)) return true;
+        q += len + (c ? 1 : 0);
+    }
+    return false;
+}
+
 static bool kv_has(const KV& kv, const char* k) { return kv.find(k) != kv.end(); }
 static std::string kv_str(const KV& kv, const char* k, const char* def = "")
 {
@@ -571,8 +588,7 @@ static int finalize_conv(accel_plan* p, Op& op)
         std::vector<_Float16> ph(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) ph[i] = (_Float16)packed[i];
         if ((rc = dev_upload(p, ph.data(), ph.size() * sizeof(_Float16), &dw_))) return rc;
-        const char* re_ = getenv("ACCEL_B3R");
-        if (!(re_ && re_[0] == '0')) {
+        if (!withheld("b3r")) {
             // the same half-rounded weights once more in MFMA fragment order [class][K step][half step][row][16] for the fp16 form
             // of conv_b3r.hip (launch geometries 76 / 77 / 79 / 80 / 81 of an f16 layer)
             const int classes = c.deconv2x ? 4 : 1, steps = c.K_pad / 32;
@@ -590,19 +606,17 @@ static int finalize_conv(accel_plan* p, Op& op)
     c.w = static_cast<const float*>(dw_);
     {
         // fp32 layers also get their weights as three bf16 planes: the bf16x3 kernel (conv_igemm.hip) is then one more
-        // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_BF16X3=0 withholds it)
-        const char* be = getenv("ACCEL_BF16X3");
+        // launch geometry (70-74) of the SAME fp32 convolution for the autotuner (ACCEL_WITHHOLD=split withholds it)
         const int ft = (int)kv_int(kv, "tile", -1);
         const bool forced = (ft >= CONV_TILE_B3 && ft < CONV_TILE_B3D + CONV_TILE_B3D_N) || (ft >= 90 && ft <= 96);
-        if (!c.f16 && c.Cin % 4 == 0 && cout_store > 4 && (!(be && be[0] == '0') || forced)) {
+        if (!c.f16 && c.Cin % 4 == 0 && cout_store > 4 && (!withheld("split") || forced)) {
             std::vector<uint16_t> pb;
             pack_bf16x3(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
             void* d3 = nullptr;
             if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d3))) return rc;
             c.wb3 = d3;
-            const char* re_ = getenv("ACCEL_B3R");
             const bool forced_r = (ft >= CONV_TILE_B3R && ft < CONV_TILE_B3D + CONV_TILE_B3D_N) || (ft >= 90 && ft <= 96);
-            if (!(re_ && re_[0] == '0') || forced_r) {      // the fragment-ordered copy for the second-generation kernel
+            if (!withheld("b3r") || forced_r) {      // the fragment-ordered copy for the second-generation kernel
                 pack_bf16x3r(packed, c.deconv2x ? 4 : 1, rows, c.K_pad, pb, c.w_plane);
                 void* d4 = nullptr;
                 if ((rc = dev_upload(p, pb.data(), pb.size() * sizeof(uint16_t), &d4))) return rc;
@@ -691,7 +705,7 @@ static int finalize_conv(accel_plan* p, Op& op)
         // half views are read / written by the fp16 form of conv_b3d.hip alone
         if (c.f16 != 1 || !c.wb3r || c.Cin % 16 || op.c.set)
             return fail(ACCEL_ERR_PLAN, "conv %s: half views need an f16-mode layer with Cin %% 16 == 0, more than 4 output channels and a "
-                                        "single output (plan option dtype=f16, ACCEL_B3R != 0)", op.name.c_str());
+                                        "single output (plan option dtype=f16, ACCEL_WITHHOLD without b3r)", op.name.c_str());
     }
     if ((size_t)op.a.N * op.a.img() * 4 > 0xFFFFFFF0ull || (size_t)op.b.N * op.b.img() * 4 > 0xFFFFFFF0ull)
         return fail(ACCEL_ERR_PLAN, "conv %s: a batched view exceeds the 4 GiB a buffer resource can address", op.name.c_str());
@@ -726,9 +740,8 @@ static int finalize_conv(accel_plan* p, Op& op)
         return fail(ACCEL_ERR_ARG, "conv %s: launch geometry id %d is not part of this build", op.name.c_str(), c.force_tile);
     {
         // Winograd F(2x2,3x3) form of the layer (3x3 / stride 1 / dilation 1 / pad 1): weights transformed here, in
-        // double, once; offered to the autotuner beside the direct tiles (ACCEL_WINOGRAD=0 withholds it)
-        const char* we = getenv("ACCEL_WINOGRAD");
-        const bool want = !(we && we[0] == '0') || c.force_tile == CONV_TILE_WINO;
+        // double, once; offered to the autotuner beside the direct tiles (ACCEL_WITHHOLD=winograd withholds it)
+        const bool want = !withheld("winograd") || c.force_tile == CONV_TILE_WINO;
         c.M = op.a.N * c.Ho * c.Wo;
         if (want && !cols && cin == cin_pad && conv_wino_eligible(c)) {
             c.wino_rows = conv_wino_rows(cout_store);
@@ -738,22 +751,11 @@ static int finalize_conv(accel_plan* p, Op& op)
             if ((rc = dev_upload(p, wu.data(), wu.size() * sizeof(float), &du))) return rc;
             c.wu = static_cast<const float*>(du);
             c.wu_bytes = (unsigned)(wu.size() * sizeof(float));
-            const char* be = getenv("ACCEL_BF16X3");
-            const char* wbe = getenv("ACCEL_WINOGRAD_B3");
             // accuracy budget: Winograd evaluations carry about 3x the rounding error of a direct one, and the plan decides which
-            // layers may take the bf16 form (conv key wb3=0 withholds it; ACCEL_WB3_SKIP = comma-separated name fragments, diagnostics)
-            bool wb3_ok = kv_int(kv, "wb3", 1) != 0;
-            if (const char* sk = getenv("ACCEL_WB3_SKIP")) {
-                std::string all(sk); size_t a0_ = 0;
-                while (a0_ <= all.size()) {
-                    size_t e_ = all.find(',', a0_); if (e_ == std::string::npos) e_ = all.size();
-                    const std::string frag = all.substr(a0_, e_ - a0_);
-                    if (!frag.empty() && op.name.find(frag) != std::string::npos) wb3_ok = false;
-                    a0_ = e_ + 1;
-                }
-            }
+            // layers may take the split form (conv key wb3=0 withholds it)
+            const bool wb3_ok = kv_int(kv, "wb3", 1) != 0;
             const bool wb3_forced = c.force_tile == CONV_TILE_WINO_B3 || c.force_tile == CONV_TILE_WINO_B3U || c.force_tile == CONV_TILE_WINO_B3S;
-            if (((!(be && be[0] == '0') && !(wbe && wbe[0] == '0') && wb3_ok) || wb3_forced) && !c.f16 && conv_wino_b3_eligible(c)) {
+            if (((!withheld("split") && !withheld("winograd_split") && wb3_ok) || wb3_forced) && !c.f16 && conv_wino_b3_eligible(c)) {
                 // the same transformed weights as three exact bf16 planes in MFMA fragment order: launch geometry 41
                 std::vector<unsigned short> ub;
                 conv_wino_b3_pack(w->data.data(), cout, cin, c.wino_rows, ub);
@@ -780,8 +782,7 @@ static int finalize_conv(accel_plan* p, Op& op)
     }
     {
         // direct stem kernel (7x7 / stride 2 / pad 3, 3-channel image, 64 output channels): per-lane weight arrangement
-        const char* se = getenv("ACCEL_STEM");
-        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_STEM || c.force_tile == CONV_TILE_STEM_B3;
+        const bool want = !withheld("stem") || c.force_tile == CONV_TILE_STEM || c.force_tile == CONV_TILE_STEM_B3;
         c.Cout_store = cout_store;
         c.res = op.d.set ? op.d.ptr : nullptr;
         if (want && !cols && cin == 3 && cout == 64 && conv_stem_eligible(c)) {
@@ -790,9 +791,7 @@ static int finalize_conv(accel_plan* p, Op& op)
             void* dsw = nullptr;
             if ((rc = dev_upload(p, ws.data(), ws.size() * sizeof(float), &dsw))) return rc;
             c.wstem = static_cast<const float*>(dsw);
-            const char* be_ = getenv("ACCEL_BF16X3");
-            const char* sb_ = getenv("ACCEL_STEM_B3");
-            if ((!(be_ && be_[0] == '0') && !(sb_ && sb_[0] == '0')) || c.force_tile == CONV_TILE_STEM_B3) {
+            if ((!withheld("split") && !withheld("stem_split")) || c.force_tile == CONV_TILE_STEM_B3) {
                 // the same layer for the bf16 matrix cores: three exact bf16 planes in MFMA fragment order (launch geometry 51)
                 std::vector<unsigned short> wb;
                 conv_stem_b3_pack(w->data.data(), cout, wb);
@@ -817,9 +816,8 @@ static int finalize_conv(accel_plan* p, Op& op)
         }
     }
     {
-        // weight-stationary streaming kernel for the 1x1 expand layers with K = 64 / 128 (ACCEL_WS1X1=0 withholds it)
-        const char* se = getenv("ACCEL_WS1X1");
-        const bool want = !(se && se[0] == '0') || c.force_tile == CONV_TILE_WS;
+        // weight-stationary streaming kernel for the 1x1 expand layers with K = 64 / 128 (ACCEL_WITHHOLD=ws1x1 withholds it)
+        const bool want = !withheld("ws1x1") || c.force_tile == CONV_TILE_WS;
         c.y2 = op.c.set ? op.c.ptr : nullptr;
         if (want && !cols && cin == cin_pad && conv_ws_eligible(c)) {
             std::vector<float> ww(conv_ws_pack_floats(cin, cout_store), 0.f);
@@ -1430,11 +1428,11 @@ static int autotune_plan(accel_plan* p)
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
                                         CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
-            const char* nd = getenv("ACCEL_TUNE_NO_DEEP");
+            const bool no_deep = withheld("deep");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && t < CONV_TILE_B3R && !nb3) continue;
                 if (t >= CONV_TILE_B3R && !c.wb3r) continue;
-                if (nd && nd[0] == '1' && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
+                if (no_deep && t >= 31 && t <= 35) continue;   // A/B switch: leave the deep-prefetch variants out
                 if (c.K_pad % conv_tile_bk(t)) continue;      // BK-64 variants need K_pad % 64 == 0
                 if (c.f16 && !(t <= 3 || t == 10 || (c.f16 == 1 && t >= CONV_TILE_B3R && c.wb3r))) continue;
                 cs.push_back({t, 0, 0});
@@ -1482,10 +1480,7 @@ static int autotune_plan(accel_plan* p)
     hipEvent_t e0 = ts.e0, e1 = ts.e1;
     int rc = 0;
     const size_t scrub_bytes = (size_t)320 << 20;      // > L2 (8 x 4 MB) + Infinity Cache (256 MB)
-    {
-        const char* e = getenv("ACCEL_TUNE_COLD");
-        if (!(e && e[0] == '0') && hipMalloc(&ts.scrub, scrub_bytes) != hipSuccess) ts.scrub = nullptr;
-    }
+    if (hipMalloc(&ts.scrub, scrub_bytes) != hipSuccess) ts.scrub = nullptr;
     void* const scrub = ts.scrub;
     for (size_t i = 0; i < p->ops.size() && !rc; ++i) {
         if (cands[i].empty()) continue;
@@ -1543,7 +1538,7 @@ static int autotune_plan(accel_plan* p)
             it = g_tune_cache.insert({key, bv}).first;
             tuned_any = true;
             ++g_tune_timed;
-            if (getenv("ACCEL_TUNE_VERBOSE"))
+            if (e && !strcmp(e, "verbose"))
                 fprintf(stderr, "[accel tune] %s: timed (not in a table): Cin %d Cout_store %d k %dx%d M %d -> geometry %d\n", op.name.c_str(),
                         c.Cin, c.Cout_store, c.kh, c.kw, c.M, bv.tile);
         } else {

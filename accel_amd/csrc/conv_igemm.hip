@@ -1080,8 +1080,7 @@ static hipError_t launch_b3(const ConvParams& p0, hipStream_t st)
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), lds); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>), lds); e != hipSuccess) return e;
     dim3 grid(p.MT * p.NT, p.deconv2x ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
-    static const char* nofast = getenv("ACCEL_B3_NOFAST");      // debugging: the general (per-lane table) load path for every layer
-    if (p.Cin % 32 == 0 && !(nofast && nofast[0] == '1')) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
+    if (p.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, true>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     else hipLaunchKernelGGL((conv_igemm_b3_kernel<BM, BN, WGM, WGN, WDMA, false>), grid, dim3(64 * WGM * WGN), lds, st, p, p.w_plane);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit <= 1) return e;

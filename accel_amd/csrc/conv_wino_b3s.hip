@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
     unsigned g_off[4];
     int g_dst[4];
     f32x4 g[4];
+#ifdef WKO_NO_LOADG
+    for (int i = 0; i < 4; ++i) g[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
     {
         const float inv_rw = 1.0f / (float)RW;
 #pragma unroll
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
     const int v_dst0 = j * VPSS + tl * BKS + ((q ^ lsw) << 2);
     const float sb = j == 1 ? 1.f : -1.f;
     auto load_g = [&](int k) {
+#ifdef WKO_NO_LOADG
+        return;
+#endif
         const unsigned ko = (unsigned)(kb + min(k, nk - 1)) * (BKS * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = buf_load4(xr, g_off[i] != OOB ? g_off[i] + ko : OOB);
@@ -116,6 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(rawS + g_dst[i]) = g[i];
     };
     auto transform = [&](int stage, int it) {
+#ifdef WKO_NO_XFORM
+        return;
+#endif
         float* vs = smem + stage * VSTS + (it ? v_dst0 + (((q ^ lsw) & 2) ? -8 : 8) : v_dst0);
         f32x4 d[4];
 #pragma unroll
@@ -126,7 +135,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float t = i == 0 ? d[0][c] - d[2][c] : i == 1 ? d[1][c] + d[2][c] : i == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c];
+#ifdef WKO_XFORM_COPY
+                vo[c] = d[i][c];
+#else
                 vo[c] = fmaf(sb, quad_2211s(t), t);
+#endif
             }
             *reinterpret_cast<f32x4*>(vs + i * 4 * VPSS) = vo;
         }
@@ -143,18 +156,34 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
     const unsigned u_step = 16u * u_pos;
     const unsigned u_plane = (unsigned)nk_all * u_step;
     i32x4 fb[4][NPW];       // weight fragments of four consecutive phases, each requested four phases (half a K step) ahead
+#ifdef WKO_NO_LOADB
+    for (int i = 0; i < 4; ++i) for (int pl = 0; pl < NPW; ++pl) fb[i][pl] = i32x4{0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};
+#endif
     auto load_b = [&](int buf, int k, int pos, int jj) {
+#ifdef WKO_NO_LOADB
+        return;
+#endif
         const unsigned so = (unsigned)(kb + min(k, nk - 1)) * u_step + (unsigned)pos * u_pos + (unsigned)jj * 1024u;
 #pragma unroll
         for (int pl = 0; pl < NPW; ++pl) fb[buf][pl] = __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, so + (unsigned)pl * u_plane, 0);
     };
     f32x4 raw[2];
+#ifdef WKO_NO_READRAW
+    raw[0] = raw[1] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
     auto read_raw = [&](int stage, int pos) {
+#ifdef WKO_NO_READRAW
+        return;
+#endif
         const float* v = smem + stage * VSTS + pos * VPSS;
         raw[0] = *reinterpret_cast<const f32x4*>(v + a_rd0);
         raw[1] = *reinterpret_cast<const f32x4*>(v + (a_rd0 ^ 4));
     };
     auto split_raw = [&](i32x4 (&a)[NPW]) {
+#ifdef WKO_NO_SPLIT
+        a[0] = __builtin_bit_cast(i32x4, raw[0]); a[NPW - 1] = __builtin_bit_cast(i32x4, raw[1]);
+        return;
+#endif
         if constexpr (H2) {
             f16x8s h, l;
 #pragma unroll
@@ -184,6 +213,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pi][jj][e] = 0.f;
     auto mma = [&](int pi, int jj, int buf, const i32x4 (&a)[NPW]) {
+#ifdef WKO_NO_MMA
+        asm volatile("" :: "v"(fb[buf][0]), "v"(fb[buf][NPW - 1]), "v"(a[0]), "v"(a[NPW - 1]));
+        return;
+#endif
         if constexpr (H2) {      // the two cross terms, then hi * hi
             constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
@@ -198,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
                                                                       __builtin_bit_cast(bf16x8s, a[PA[t] % NPW]), acc[pi][jj], 0, 0, 0);
         }
     };
+#ifdef WKO_NO_BARRIER
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+#else
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#endif
 
     const int P0 = 4 * wave;
     i32x4 aA[NPW], aB[NPW];
@@ -294,6 +331,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_b3s_kernel(ConvParams p)
 #undef WS_FENCE
 #undef WS_INTERLEAVE
 
+#ifdef WKO_NO_EPI
+    {
+        f32x16 t = acc[0][0];
+        for (int pi = 0; pi < 4; ++pi) for (int jj = 0; jj < 2; ++jj) t += acc[pi][jj];
+        if (p.slope == 12345.f) for (int e = 0; e < 16; ++e) p.y[threadIdx.x * 16 + e] = t[e];
+        return;
+    }
+#endif
     // ---- exchange + output transform + epilogue ----
     const int et = tid >> 3, ecq = tid & 7;                 // this thread finishes tile et, channels 4*ecq .. +3 of each round
     const int en = un, ety = uty0 + (et >> bws), etx = utx0 + (et & BWm);

@@ -44,22 +44,22 @@ struct ConvParams {
     unsigned w_bytes;      // bytes of one weight class
     const int4* ktab;      // per K step (and parity class): {dy, dx, input byte offset, 0}; null -> generic path
     // Winograd F(2x2,3x3) variant (conv_wino.hip, tile id 40): host-transformed weights [C/8][16][wino_rows][8]
-    const float* wu;       // null: the layer has no Winograd form (or ACCEL_WINOGRAD=0)
+    const float* wu;       // null: the layer has no Winograd form (or ACCEL_WITHHOLD=winograd)
     unsigned wu_bytes;
     int wino_rows;         // output-channel rows of wu (Cout_store rounded up to the block's 64)
     int wino_T;            // 2x2 output tiles = M / 4, filled by the launcher
     int wino_bhs;          // geometry 42: log2 of the tile-block height (3 / 2 / 1 = 8x8 / 4x16 / 2x32 tiles), filled by the launcher
     // direct 7x7/2 stem variant (conv_stem.hip, tile id 50): weights pre-arranged per lane
-    const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_STEM=0)
+    const float* wstem;    // null: not a 3-channel 7x7/2 stem (or ACCEL_WITHHOLD=stem)
     const void* wstemb;    // the same layer on the bf16 matrix cores (conv_stem_b3.hip, tile id 51): three bf16 planes in fragment order; null: not offered
     // weight-stationary streaming 1x1 variant (conv_1x1ws.hip, tile id 60): weights as the LDS image per column group
     // bf16x3 variant of an fp32 layer (launch geometries 70-74): the weights once more, split into three bf16 planes
-    const void* wb3;       // null: Cin % 8 != 0, narrow output, or ACCEL_BF16X3=0
-    const float* wws;      // null: not a 64 -> k*256 / 128 -> k*128 1x1 stride-1 layer (or ACCEL_WS1X1=0)
+    const void* wb3;       // null: Cin % 8 != 0, narrow output, or ACCEL_WITHHOLD=split
+    const float* wws;      // null: not a 64 -> k*256 / 128 -> k*128 1x1 stride-1 layer (or ACCEL_WITHHOLD=ws1x1)
     unsigned wws_bytes;
     // second-generation bf16x3 kernel (conv_b3r.hip, launch geometries 76, 77, 79, 80, 81): the three bf16 planes once more, in MFMA
     // fragment order [class][K step][half step][row][16] (weights go global -> VGPR, never through LDS)
-    const void* wb3r;      // null where wb3 is null (or ACCEL_B3R=0)
+    const void* wb3r;      // null where wb3 is null (or ACCEL_WITHHOLD=b3r)
     const void* wub;       // conv_wino_b3.hip: U = G g G^T as three bf16 planes [plane][C/16][16][wino_rows][16]; null: not offered
     unsigned wub_bytes;
     // fp16x2 form of the bf16x3 kernels ("h2", ConvParams::f16 == 3 inside the launchers): every fp32 operand as hi + lo, two half

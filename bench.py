@@ -46,7 +46,7 @@ def parse():
                          "expanded on the root into the same fp32 logits + labels bit for bit (accel_gather_scores; falls back to logits when the "
                          "model's upsampling filters are not uniform); logits: the 159 MB fp32 logits themselves (link-bound beyond ~480 frames/s "
                          "per GPU, DESIGN.md 6); labels: the uint8 label maps")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("ACCEL_BENCH_BATCH", "8")),
+    ap.add_argument("--batch", type=int, default=8,
                     help="clips processed together per GPU: every call runs one frame of each of B independent clips, the "
                          "convolutions see M = B*Ho*Wo (BASELINE config 4 shards 8 clips per GPU); 1 = the reference's batch")
     ap.add_argument("--dtype", default=os.environ.get("ACCEL_CONV_DTYPE", "f32"), choices=["f32", "f16", "bf16x3"],
@@ -57,10 +57,14 @@ def parse():
     ap.add_argument("--secondary", default="auto", choices=["auto", "none"],
                     help="auto: on a single GPU with the headline configuration also measure Accel-101, batch 1 and the "
                          "PCIe-inclusive loop (reported under `secondary`); none: headline only")
-    ap.add_argument("--root-relief", type=int, default=int(os.environ.get("ACCEL_BENCH_ROOT_RELIEF", "-1")),
+    ap.add_argument("--root-relief", type=int, default=-1,
                     help="N > 1 with --gather scores | logits: rank 0 (which also receives -- and with scores expands -- every other rank's frames) "
                          "processes this many clips fewer per call than the other ranks (dist.shard_clips(..., root_relief)); 0 = even shares; "
                          "default (-1): 1")
+    ap.add_argument("--bind-inputs", action="store_true",
+                    help="the plans read the resident frames where they lie (accel_model_bind_device) instead of copying them into the model's "
+                         "input buffers: an extension, not the reference executor's semantics; reported as secondary.*_zero_copy_inputs by default")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise torch.distributed anyway (exercises the RCCL gather path on one GPU)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, have each print its rank / world size, exit (no GPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -297,7 +301,7 @@ class Workload(object):
         self.dev_frames = [torch.from_numpy(f).cuda() for f in self.host_frames]
         self.nbytes = B * 3 * H * W * 4
         self.gather = None
-        self.bind_inputs = os.environ.get("ACCEL_BENCH_BIND_INPUTS") == "1"
+        self.bind_inputs = False      # --bind-inputs
 
     @property
     def scores_gather(self):
@@ -308,7 +312,7 @@ class Workload(object):
         m = self.model
         # the frames are resident in HBM and are COPIED into the model's input buffers every frame, as the reference's executor does
         # with a source array on the device (executor_group._load_general: d_src.copyto(d_targets), unconditionally); the headline
-        # includes those copies.  ACCEL_BENCH_BIND_INPUTS=1: the plans read the frames where they lie (accel_model_bind_device) --
+        # includes those copies.  --bind-inputs: the plans read the frames where they lie (accel_model_bind_device) --
         # reported as secondary.*_zero_copy_inputs, never as the headline
         put = m.bind_device if self.bind_inputs else m.write_device
         for t in range(self.interval):
@@ -514,7 +518,7 @@ def _run(a):
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    force_dist = os.environ.get("ACCEL_BENCH_FORCE_DIST") == "1"   # exercise the RCCL gather path on a single GPU
+    force_dist = a.force_dist   # exercise the RCCL gather path on a single GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -532,6 +536,7 @@ def _run(a):
     relief = min(a.root_relief if a.root_relief >= 0 else 1, B - 1) if (world > 1 and a.gather in ("logits", "scores")) else 0
     B_rank = B - relief if rank == 0 else B
     wl = Workload(a.version, B_rank, H, W, a.interval, local_rank, rank, config)
+    wl.bind_inputs = a.bind_inputs
 
     gather_note = "none (single GPU)"
     payload = a.gather
@@ -638,7 +643,7 @@ def _run(a):
                           "and, for most implicit-GEMM layers, 'bf16x3': each fp32 operand split EXACTLY into three bf16 terms, six bf16 "
                           "MFMA products accumulated in fp32 -- error against float64 equal to the fp32-MFMA kernel's, "
                           "tests/test_bf16x3_gpu.py; secondary.*_fp32_mfma_only = without them)")
-                         if os.environ.get("ACCEL_BF16X3", "1") != "0" else "f32 (fp32 MFMA only: ACCEL_BF16X3=0)") if a.dtype == "f32" else
+                         if "split" not in os.environ.get("ACCEL_WITHHOLD", "").split(",") else "f32 (fp32 MFMA only: ACCEL_WITHHOLD=split)") if a.dtype == "f32" else
                         "f32 as 3 x bf16 (each fp32 operand split exactly into three bf16 terms, six products per multiply-add on the bf16 "
                         "matrix cores, f32 storage + accumulate; error vs float64 equal to the fp32-MFMA kernel's, tests/test_bf16x3_gpu.py)"
                         if a.dtype == "bf16x3" else
@@ -651,7 +656,7 @@ def _run(a):
                           "frames_per_step_per_gpu": a.interval * B, "clips_per_call": B, "root_relief_clips": relief,
                           "inputs": ("frames resident in HBM, COPIED into the model's input buffers every frame (the reference executor's "
                                      "_load_general copy; device to device)" if not wl.bind_inputs else
-                                     "frames resident in HBM, read where they lie (ACCEL_BENCH_BIND_INPUTS=1: zero-copy, not the reference's semantics)"),
+                                     "frames resident in HBM, read where they lie (--bind-inputs: zero-copy, not the reference's semantics)"),
                           "parallelism": "clip-sharded x%d (weights replicated)" % world,
                           "gather": gather_note + ("; DISABLED after failure: " + gather_failures[0] if gather_failures else ""), "weights": "seeded random",
                           "lowering": ("exact linear folds on (DESIGN.md 4): feat_upsampling*fc6 composed into one deconvolution; non-key L-head fc6 "
@@ -681,7 +686,7 @@ def _run(a):
         except Exception as e:
             sec["accel18_batch%d_zero_copy_inputs" % B] = {"error": repr(e)}
         finally:
-            wl.bind_inputs = os.environ.get("ACCEL_BENCH_BIND_INPUTS") == "1"
+            wl.bind_inputs = a.bind_inputs
         sec.update(_gather_self_secondary(wl, a, B, H, W, local_rank, steps2, warm2, rate))
         try:
             el = wl.timed_pcie(steps2, warm2)
@@ -712,24 +717,24 @@ def _run(a):
                 w2.close()
             except Exception as e:
                 sec[name] = {"error": repr(e)}
-        if a.dtype == "f32" and os.environ.get("ACCEL_BF16X3", "1") != "0":
+        if a.dtype == "f32" and "split" not in os.environ.get("ACCEL_WITHHOLD", "").split(","):
             # the headline again with the fp32 MFMA for EVERY product (no bf16x3 launch geometries): the A/B of that choice
             try:
-                os.environ["ACCEL_BF16X3"] = "0"
+                os.environ["ACCEL_WITHHOLD"] = "split"
                 w3 = Workload(a.version, B, H, W, a.interval, local_rank, rank, config)
                 el = w3.timed(steps2, warm2)
                 rf = w3.conv_roofline(a.dtype)
                 sec["accel18_batch%d_fp32_mfma_only" % B] = {
                     "value": rate(w3, el, steps2), "unit": "frames/s", "clips_per_call": B,
-                    "what": "the headline workload with ACCEL_BF16X3=0: every multiply-add on v_mfma_f32_* (Winograd where it wins), "
+                    "what": "the headline workload with ACCEL_WITHHOLD=split: every multiply-add on v_mfma_f32_* (Winograd where it wins), "
                             "no 3 x bf16 split launch geometries",
                     "conv_algorithmic_tflops": rf["all_conv"]["algorithmic_tflops"], "conv_executed_frac_of_peak": rf["all_conv"]["frac"]}
                 w3.close()
             except Exception as e:
                 sec["accel18_batch%d_fp32_mfma_only" % B] = {"error": repr(e)}
             finally:
-                os.environ.pop("ACCEL_BF16X3", None)
-        if a.dtype == "f32" and os.environ.get("ACCEL_BF16X3", "1") != "0" and os.environ.get("ACCEL_SPLIT", "h2") == "h2":
+                os.environ.pop("ACCEL_WITHHOLD", None)
+        if a.dtype == "f32" and "split" not in os.environ.get("ACCEL_WITHHOLD", "").split(",") and os.environ.get("ACCEL_SPLIT", "h2") == "h2":
             # the headline again with the range-free three-term bf16 split (six products) instead of fp16x2 (three): the A/B of the form
             try:
                 os.environ["ACCEL_SPLIT"] = "b3"

@@ -28,7 +28,7 @@ PY
   wc -l $ACCEL_TUNE_CACHE
   exit 0
 fi
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> gpurun_out/tune_table.err          # Accel-18 B=8, B=1, Accel-101 B=8, and B=8 with ACCEL_BF16X3=0
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>> gpurun_out/tune_table.err          # Accel-18 B=8, B=1, Accel-101 B=8, and B=8 with ACCEL_WITHHOLD=split
 for v in 34 50 101; do
   python bench.py --version $v --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --secondary none > /dev/null 2>> gpurun_out/tune_table.err
 done

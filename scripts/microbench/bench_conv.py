@@ -81,6 +81,8 @@ if __import__('os').environ.get("BATCH4"):   # what would batching 4 frames buy?
     for (n, ci, co, h, w, k, st, pd, dl, rs) in base:
         SHAPES.append((n + " x1", ci, co, h, w, k, st, pd, dl, rs, "conv"))
         SHAPES.append((n + " x4", ci, co, 4 * h, w, k, st, pd, dl, rs, "conv"))
+if __import__('os').environ.get("ONLY"):     # keep the shapes whose name holds one of the comma-separated fragments
+    SHAPES = [sh for sh in SHAPES if any(f in sh[0] for f in __import__('os').environ["ONLY"].split(","))]
 ctx = runtime.Context(0)
 tiles = [int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else [-1]
 for (name, cin, cout, H, W, k, s, p, d, res, mode) in SHAPES:

@@ -20,6 +20,6 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_${R}_pmc2 -o bench --output-format csv -
 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_${R}_pmc3 -o bench --output-format csv -- $B > /dev/null 2>&1
 cd $REPO
 python scripts/microbench/prof_ops.py 18 > $OUT/ops18_${R}.txt 2>&1
-python scripts/microbench/prof_ops.py 18 ${ACCEL_BENCH_BATCH:-8} > $OUT/ops18_${R}_b8.txt 2>&1
-python scripts/summarize_rocprof.py $OUT/prof_$R $OUT/prof_${R}_pmc1 $OUT/prof_${R}_pmc2 $OUT/prof_${R}_pmc3 $OUT/pmc_traffic_$R.json batch=${ACCEL_BENCH_BATCH:-8} > $OUT/rocprof_summary_$R.md
+python scripts/microbench/prof_ops.py 18 8 > $OUT/ops18_${R}_b8.txt 2>&1
+python scripts/summarize_rocprof.py $OUT/prof_$R $OUT/prof_${R}_pmc1 $OUT/prof_${R}_pmc2 $OUT/prof_${R}_pmc3 $OUT/pmc_traffic_$R.json batch=8 > $OUT/rocprof_summary_$R.md
 tail -3 $OUT/bench_${R}_final.json | cut -c1-300

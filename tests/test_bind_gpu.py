@@ -9,7 +9,6 @@ pytestmark = pytest.mark.gpu
 
 def _logits_of_a_step(wl, monkeypatch, copy):
     import torch
-    monkeypatch.setenv("ACCEL_BENCH_COPY_INPUTS", "1" if copy else "0")
     outs = []
     m = wl.model
     put = m.write_device if copy else m.bind_device

@@ -612,6 +612,26 @@ def test_shipped_tune_table_loads():
     assert shipped == len(lines) - 1 and timed == 0
 
 
+def test_environment_switches_are_few_and_every_one_is_documented():
+    """the product tree reads at most 20 ACCEL_* environment switches, each listed in INTEGRATION.md's table (kernel families are
+    withheld through ONE list, ACCEL_WITHHOLD; bench.py takes its options as flags)"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, "accel_amd", "csrc", "*")) + glob.glob(os.path.join(root, "accel_amd", "**", "*.py"), recursive=True):
+        if f.endswith((".cpp", ".hip", ".h", ".py")):
+            src = open(f).read()
+            found |= set(re.findall(r'getenv\("(ACCEL_[A-Z0-9_]+)"\)', src))
+            found |= set(re.findall(r'environ(?:\.get|\.setdefault)?[\(\[]\s*"(ACCEL_[A-Z0-9_]+)"', src))
+    assert 10 < len(found) <= 20, sorted(found)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [k for k in sorted(found) if "`" + k not in doc]
+    assert not missing, "not in INTEGRATION.md's switch table: %s" % missing
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert set(re.findall(r'"(ACCEL_BENCH_[A-Z_]+)"', bench)) | set(re.findall(r'(ACCEL_BENCH_[A-Z_]+)=', bench)) <= {"ACCEL_BENCH_SELF_LAUNCHED"}
+
+
 _REF_CFGS = "/root/reference/experiments/dff_deeplab/cfgs"
 
 
