@@ -216,7 +216,7 @@ def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
     check_against_oracle(outs, ref, "config3 accel-101 1024x2048")
 
 
-@pytest.mark.parametrize("version", ["34", "50"])
+@pytest.mark.parametrize("version", [pytest.param("34", marks=pytest.mark.gpu_extra), "50"])      # (34 at 128x256: test_graph_gpu.py)
 def test_accel34_accel50_1024x2048_vs_oracle(demo_cfg, version):
     """The other two models at the size the reference validates at: a key and a non-key frame against the CPU oracle."""
     from accel_amd import demo
