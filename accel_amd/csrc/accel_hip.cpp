@@ -1427,7 +1427,7 @@ static int autotune_plan(accel_plan* p)
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,
-                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 2, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
+                                        CONV_TILE_B3R, CONV_TILE_B3R + 1, CONV_TILE_B3R + 3, CONV_TILE_B3R + 4, CONV_TILE_B3R + 5};
             const bool no_deep = withheld("deep");
             for (int t : tiles) {
                 if (t >= CONV_TILE_B3 && t < CONV_TILE_B3R && !nb3) continue;

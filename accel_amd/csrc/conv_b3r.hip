@@ -306,7 +306,6 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
         switch (tile) {
             case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4, 0, 1>(p, st);
             case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2, 0, 1>(p, st);
-            case CONV_TILE_B3R + 2: return launch_b3r<128, 32, 4, 1, 0, 1>(p, st);
             case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 1>(p, st);
             case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 1>(p, st);
             case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 1>(p, st);
@@ -317,7 +316,6 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
         switch (tile) {
             case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4, 0, 2>(p, st);
             case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2, 0, 2>(p, st);
-            case CONV_TILE_B3R + 2: return launch_b3r<128, 32, 4, 1, 0, 2>(p, st);
             case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 2>(p, st);
             case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 2>(p, st);
             case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 2>(p, st);
@@ -327,7 +325,6 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
     switch (tile) {
         case CONV_TILE_B3R: return launch_b3r<128, 128, 2, 4>(p, st);
         case CONV_TILE_B3R + 1: return launch_b3r<128, 64, 2, 2>(p, st);       // 64-channel layers (res2, the ResNet-18 trunk's first stage)
-        case CONV_TILE_B3R + 2: return launch_b3r<128, 32, 4, 1>(p, st);       // strips of at most 32 output channels (the offset branches of res5, score)
         case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4>(p, st);
         case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8>(p, st);      // every wavefront owns 32 columns: no weight fragment is fetched twice
         case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4>(p, st);

@@ -1129,7 +1129,7 @@ bool conv_tile_valid(int tile)
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
     return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS ||
-           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 2 && tile <= CONV_TILE_B3R + 5) ||
+           (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5) ||
            (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N);
 }
 
@@ -1140,7 +1140,6 @@ static void tile_dims(int tile, int& bm, int& bn)
     if (tile == CONV_TILE_B3 + 5) { bm = 256; bn = 128; return; }
     if (tile == CONV_TILE_B3R || (tile >= 90 && tile <= 96)) { bm = 128; bn = 128; return; }
     if (tile == CONV_TILE_B3R + 1) { bm = 128; bn = 64; return; }
-    if (tile == CONV_TILE_B3R + 2) { bm = 128; bn = 32; return; }
     if (tile == CONV_TILE_B3R + 3 || tile == CONV_TILE_B3R + 4) { bm = 128; bn = 256; return; }
     if (tile == CONV_TILE_B3R + 5) { bm = 128; bn = 128; return; }
     if (tile == CONV_TILE_B3D || tile == CONV_TILE_B3D + 4) { bm = 256; bn = 256; return; }

@@ -120,7 +120,7 @@ void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
-#define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 78 = 128x32 / 4x1, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
+#define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);
 #define CONV_TILE_B3D 82                 // conv_b3d.hip (f16-mode layers only; both operands by LDS-DMA, fp32 or half views): 82 = 256x256 / 4x2 wavefronts,
                                          // 83 = 128x256 / 4x2, 84 = 128x128 / 4x1, 85 = 128x128 / 2x2, 88 = 128x64 / 4x1, 89 = 256x128 / 4x2 (86 / 87 retired)
