@@ -1398,7 +1398,10 @@ static int autotune_plan(accel_plan* p)
             }
         }
         else if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
-        else if (c.Cout_store <= 32) { cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0}); }
+        else if (c.Cout_store <= 32) {
+            cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0});
+            if (c.wh2r && conv_halo_eligible(c)) cs.push_back({CONV_TILE_HALO, 0, 1});      // the offset branches of res5 (conv_halo.hip)
+        }
         else {
             // (a layer that runs in fp16-MFMA mode stays on the fp16 kernel: "operands of every convolution with Cin % 8 == 0 and
             // more than 4 output channels are rounded to half" is then the exact specification of the mode, which the oracle
@@ -1424,6 +1427,7 @@ static int autotune_plan(accel_plan* p)
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wstemb && !c.f16) cs.push_back({CONV_TILE_STEM_B3, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
+            if (c.wh2r && !c.f16 && conv_halo_eligible(c)) cs.push_back({CONV_TILE_HALO, 0, 1});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,

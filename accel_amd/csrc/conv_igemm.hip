@@ -1128,7 +1128,7 @@ bool conv_tile_valid(int tile)
 #ifdef ACCEL_CONV_DIAG
     if ((tile >= 20 && tile <= 30) || (tile >= 90 && tile <= 96)) return true;
 #endif
-    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS ||
+    return (tile >= 0 && tile <= 19) || (tile >= 31 && tile <= 35) || tile == CONV_TILE_WINO || tile == CONV_TILE_WINO_B3 || tile == CONV_TILE_WINO_B3U || tile == CONV_TILE_WINO_B3S || tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS || tile == CONV_TILE_HALO ||
            (tile >= CONV_TILE_B3 && tile < CONV_TILE_B3 + 8) || (tile >= CONV_TILE_B3R + 3 && tile <= CONV_TILE_B3R + 5) ||
            (tile >= CONV_TILE_B3D && tile < CONV_TILE_B3D + CONV_TILE_B3D_N);
 }
@@ -1162,7 +1162,7 @@ size_t conv_plan_split(ConvParams& p)
     if (p.no_split || p.narrow) return 0;
     int bm, bn;
     const int tile = conv_pick_tile(p);
-    if (tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS) return 0;
+    if (tile == CONV_TILE_STEM || tile == CONV_TILE_STEM_B3 || tile == CONV_TILE_WS || tile == CONV_TILE_HALO) return 0;
     if (tile == CONV_TILE_WINO) {
         // Winograd blocks own 64 tiles (256 pixels) x 64 channels; the K loop runs in steps of 8 channels, unrolled by 2.
         // Splitting it over blockIdx.y leaves raw partial OUTPUTS (the output transform is linear) that the ordinary
@@ -1246,6 +1246,16 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         return launch_conv_stem_b3(p, st);
     }
     if (p.force_tile == CONV_TILE_WS) return launch_conv_ws(p, st);
+    if (p.force_tile == CONV_TILE_HALO) {      // fp16x2 form only: the two half planes of conv_b3r.hip
+        if (p.f16 || !p.wh2r || p.x_half || p.y_half || p.res_half) return hipErrorInvalidValue;
+        ConvParams q = p;
+        q.w = static_cast<const float*>(p.wh2r);
+        q.w_bytes = p.w_bytes / 2;
+        q.scale = p.scale_h2;
+        q.xr = p.xr_slot;
+        q.f16 = 3;
+        return launch_conv_halo(q, st);
+    }
     const int b3d_tile = (p.force_tile < 0 && (p.x_half || p.y_half || p.res_half)) ? conv_pick_tile(p) : p.force_tile;
     if (b3d_tile >= CONV_TILE_B3D && b3d_tile < CONV_TILE_B3D + CONV_TILE_B3D_N) {
         // conv_b3d.hip: the one-plane fp16 form of an f16-mode layer, both operands by LDS-DMA (fp32 / half views)

@@ -119,6 +119,9 @@ bool conv_stem_eligible(const ConvParams& p);
 void conv_stem_pack(const float* w, int Cout, float* out);
 int conv_stem_pack_floats();
 hipError_t launch_conv_stem(const ConvParams& p, hipStream_t st);
+#define CONV_TILE_HALO 78                // conv_halo.hip: 3x3 / stride 1 / dilation 1 or 2 layers with few output channels, the patch staged once with its halo (fp16x2 form only)
+bool conv_halo_eligible(const ConvParams& p);
+hipError_t launch_conv_halo(const ConvParams& p, hipStream_t st);
 #define CONV_TILE_B3 70                  // 70..75: the bf16x3 kernel (fp32 values, bf16 matrix cores) at geometry 0, 1, 2, 3, 10 and 256x128
 #define CONV_TILE_B3R 76                 // conv_b3r.hip: 76 = 128x128 / 2x4 wavefronts, 77 = 128x64 / 2x2, 79 = 128x256 / 2x4, 80 = 128x256 / 1x8, 81 = 128x128 / 1x4
 hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st);

@@ -5,7 +5,7 @@ set -e
 N=$1; F=$2
 D=build/ab/$N
 mkdir -p $D
-for f in conv_igemm conv_b3r conv_b3d conv_wino conv_wino_b3 conv_wino_b3s conv_stem conv_stem_b3 conv_1x1ws misc; do
+for f in conv_igemm conv_b3r conv_b3d conv_wino conv_wino_b3 conv_wino_b3s conv_stem conv_stem_b3 conv_1x1ws conv_halo misc; do
   (hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w $F -c accel_amd/csrc/$f.hip -o $D/$f.o) &
 done
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -w $F -x hip -c accel_amd/csrc/accel_hip.cpp -o $D/accel_hip.o &

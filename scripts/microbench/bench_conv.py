@@ -82,10 +82,12 @@ if __import__('os').environ.get("BATCH4"):   # what would batching 4 frames buy?
         SHAPES.append((n + " x1", ci, co, h, w, k, st, pd, dl, rs, "conv"))
         SHAPES.append((n + " x4", ci, co, 4 * h, w, k, st, pd, dl, rs, "conv"))
 if __import__('os').environ.get("STRIP"):    # layers with at most 72 output channels at 8 clips per call: the offset branches of res5, the score layer
-    SHAPES = [("res5 offset 3x3 512-18 x8", 512, 18, 512, 128, 3, 1, 1, 1, 0, "conv"),
-              ("r18 res5 offset 3x3 512-72 @32x64 x8", 512, 72, 256, 64, 3, 1, 1, 1, 0, "conv"),
-              ("score 1x1 1024-19 x8", 1024, 19, 512, 128, 1, 1, 0, 1, 0, "conv"),
-              ("res5 offset 3x3 512-18 x1", 512, 18, 64, 128, 3, 1, 1, 1, 0, "conv")]
+    SHAPES = [("res5 offset 3x3 d2 512-18 x8", 512, 18, 512, 128, 3, 1, 2, 2, 0, "conv"),
+              ("r18 res5 offset 3x3 d2 512-72 @32x64 x8", 512, 72, 256, 64, 3, 1, 2, 2, 0, "conv"),
+              ("res5 offset 3x3 d2 512-18 x1", 512, 18, 64, 128, 3, 1, 2, 2, 0, "conv"),
+              ("r18 res5 offset 3x3 d2 512-72 @32x64 x1", 512, 72, 32, 64, 3, 1, 2, 2, 0, "conv"),
+              ("res5 offset 3x3 d1 512-18 x8", 512, 18, 512, 128, 3, 1, 1, 1, 0, "conv"),
+              ("score 1x1 1024-19 x8", 1024, 19, 512, 128, 1, 1, 0, 1, 0, "conv")]
 if __import__('os').environ.get("ONLY"):     # keep the shapes whose name holds one of the comma-separated fragments
     SHAPES = [sh for sh in SHAPES if any(f in sh[0] for f in __import__('os').environ["ONLY"].split(","))]
 ctx = runtime.Context(0)
