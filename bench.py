@@ -161,6 +161,7 @@ PIPES = {"conv_igemm_b3_kernel": (6.0, BF16_PEAK_TFLOPS, "bf16 MFMA, six product
          "conv1x1_ws_kernel": (1.0, MFMA_F32_PEAK_TFLOPS, "fp32 MFMA (weight-stationary streaming 1x1)"),
          "conv_stem_b3_kernel": (6.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "bf16 MFMA, the 7x7/2 stems as six bf16 products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic)"),
          "conv_stem_h2_kernel": (3.0 * 176.0 / 147.0, BF16_PEAK_TFLOPS, "fp16 MFMA, the 7x7/2 stems as three half products per multiply-add over K = 7 x 24 padded to 176 (147 algorithmic): conv_stem_b3<H2>"),
+         "conv_halo_h2_kernel": (3.0, BF16_PEAK_TFLOPS, "fp16 MFMA, THREE products per fp32 multiply-add: conv_halo.hip (geometry 78: 3x3 layers with few output channels, the patch staged once with its halo)"),
          "conv_h2_kernel": (3.0, BF16_PEAK_TFLOPS, "fp16 MFMA (same dense peak as bf16), THREE products per fp32 multiply-add (two half terms per operand, hi*hi + hi*lo + lo*hi): conv_b3r<NPL=2>"),
          "conv_wino_h2_kernel": (3.0 / 2.25, BF16_PEAK_TFLOPS, "fp16 MFMA, Winograd F(2x2,3x3) position GEMMs as three half products each (conv_wino_b3 / conv_wino_b3s, H2)"),
          "conv_f16_kernel": (1.0, BF16_PEAK_TFLOPS, "fp16 MFMA, ONE half product per multiply-add (f16-mode layer on any geometry: conv_igemm_f16 / conv_b3r<NPL=1> / conv_b3d<NPL=1>)")}
@@ -178,6 +179,8 @@ def conv_family(op, dtype="f32"):
         return "conv_f16_kernel"
     if t in (41, 42, 43):
         return "conv_wino_h2_kernel" if mode == 3 else "conv_wino_b3_kernel"
+    if mode == 3 and t == 78:
+        return "conv_halo_h2_kernel"
     if mode == 3 and 76 <= t <= 81:
         return "conv_h2_kernel"
     if t == 40:

@@ -75,7 +75,7 @@ def main():
             ww = sum(v.get("WRITE_SIZE", 0) for k, v in wr.items() if sel(k)) * 1024
             nwr = sum(n for k, n in nw.items() if sel(k))
             return {"kernels": list(fams), "read_bytes_per_launch": rd / max(nr, 1), "write_bytes_per_launch": ww / max(nwr, 1), "launches_sampled": nr}
-        conv = ("conv_igemm_f32_kernel", "conv_igemm_b3_kernel", "conv_b3r_kernel", "conv_wino_f32_kernel", "conv_wino_b3_kernel", "conv_wino_b3s_kernel", "conv_stem_f32_kernel", "conv1x1_ws_kernel",
+        conv = ("conv_igemm_f32_kernel", "conv_igemm_b3_kernel", "conv_b3r_kernel", "conv_wino_f32_kernel", "conv_wino_b3_kernel", "conv_wino_b3s_kernel", "conv_halo_kernel", "conv_stem_f32_kernel", "conv1x1_ws_kernel",
                 "conv_narrow_kernel", "conv_narrow3x3_kernel", "conv_igemm_f16_kernel")
         dom = traffic(("conv_igemm_b3_kernel", "conv_b3r_kernel"))      # the bf16x3 implicit-GEMM family: bench.py's roofline.kernel
         allc = traffic(conv)

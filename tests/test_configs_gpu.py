@@ -216,7 +216,8 @@ def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
     check_against_oracle(outs, ref, "config3 accel-101 1024x2048")
 
 
-@pytest.mark.parametrize("version", [pytest.param("34", marks=pytest.mark.gpu_extra), "50"])      # (34 at 128x256: test_graph_gpu.py)
+@pytest.mark.parametrize("version", [pytest.param("34", marks=pytest.mark.gpu_extra), pytest.param("50", marks=pytest.mark.gpu_extra)])
+# (inside `-m gpu`: both models against the oracle at 128x256, test_graph_gpu.py; Accel-50 at 512x1024 and 2048x4096 in its f16 mode, below)
 def test_accel34_accel50_1024x2048_vs_oracle(demo_cfg, version):
     """The other two models at the size the reference validates at: a key and a non-key frame against the CPU oracle."""
     from accel_amd import demo
@@ -475,10 +476,12 @@ def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     P.update(aux)
     G.ROUND_F16, G.STORE_F16 = True, half_layers("50", H, W, demo_cfg)
     try:
-        ref = G.run_clip(P, "50", _oracle_frames(frames[:2], demo_cfg), interval)
+        # (the KEY frame at this size: two thirds of the oracle's minute and a half; the chain through warp + correction branch is checked
+        # against the same specification at 512x1024, tests/test_f16_storage_gpu.py, and here for finiteness and non-degenerate labels)
+        ref = G.run_clip(P, "50", _oracle_frames(frames[:1], demo_cfg), interval)
     finally:
         G.ROUND_F16, G.STORE_F16 = False, None
-    for t, ((b, lb), (rlg, rlab)) in enumerate(zip(outs["f16"][:2], ref)):
+    for t, ((b, lb), (rlg, rlab)) in enumerate(zip(outs["f16"][:1], ref)):
         r = rlg[0][:, ::4, ::4]
         scale = max(1.0, float(np.abs(r).max()))
         d = np.abs(b - r).ravel() / scale

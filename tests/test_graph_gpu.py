@@ -215,7 +215,7 @@ def test_deeplab_frame_by_frame_baseline(demo_cfg):
     np.testing.assert_array_equal(lab[0][safe], np.argmax(ref, axis=1)[0][safe])
 
 
-@pytest.mark.parametrize("H,W", [(256, 384), pytest.param(384, 128, marks=pytest.mark.gpu_extra), pytest.param(160, 288, marks=pytest.mark.gpu_extra), (96, 224)])
+@pytest.mark.parametrize("H,W", [(256, 384), pytest.param(384, 128, marks=pytest.mark.gpu_extra), pytest.param(160, 288, marks=pytest.mark.gpu_extra), pytest.param(96, 224, marks=pytest.mark.gpu_extra)])
 def test_other_aspect_ratios(demo_cfg, H, W):
     """sizes other than 1:2, and sizes that are multiples of 32 but not of 128 (odd FlowNet encoder sizes: the
     decoder's Crop(offset 1) then keeps 2h-1 rows of a deconvolution, resnet_v1_101_flownet_deeplab.py:1776-1801);
@@ -267,13 +267,14 @@ def test_size_not_multiple_of_16_is_rejected(demo_cfg):
         tester.release_models()
 
 
-def test_two_resolutions_in_one_process(demo_cfg):
+def test_two_resolutions_in_one_process(demo_cfg, monkeypatch):
     """a second frame size re-lowers and binds its own model (MutableModule rebinds on a shape change,
     module.py:1026-1042); results of the first size are unaffected, and the lazily bound size is CORRECT from its first
     non-key frame on: the cur plan of the new size is finalized (autotuned, warmed up, captured) between the key frame
     and the first non-key frame of the clip, which must not disturb the propagated feature."""
     from accel_amd import demo
     from accel_amd.core import tester
+    monkeypatch.setenv("ACCEL_AUTOTUNE", "0")      # (a binding test: the static launch geometries; timing 256x256's layers took 20 s of the suite)
     arg, aux = synth.model_params("18", 128, 256, demo_cfg)
     P = dict(arg)
     P.update(aux)
