@@ -446,8 +446,8 @@ def test_gather_beside_the_next_frames_compute_does_not_disturb_it(demo_cfg, mon
 
 def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     """Accel-50, fp16-MFMA convolutions with half activation storage, 2048x4096 (config 5's frame size), the first two frames of a
-    kf=10 group (key, non-key: the chain through warp + correction branch): finite logits, non-degenerate label maps, and both frames
-    against the mode's own specification (below)."""
+    kf=10 group (key, non-key: the chain through warp + correction branch): finite logits and non-degenerate label maps on both, the key
+    frame against the mode's own specification (below)."""
     from accel_amd import demo
     from accel_amd.core import tester
     H, W, interval = 2048, 4096, 10
