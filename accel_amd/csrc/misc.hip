@@ -221,6 +221,8 @@ __device__ __forceinline__ void flow_warp_body(const float* __restrict__ feat, i
                                                float* __restrict__ out, int oCs, int C4, int H, int W,
                                                float* __restrict__ out2, int o2Cs, const float* __restrict__ bias, unsigned& m1, unsigned& m2)
 {
+    // (measured and not adopted, profiles/r05_ab_xcd_mapping.log: consecutive pixels on ONE XCD -- the mapping that helps dcn_cols9 below --
+    // makes this kernel slower, 231 -> 276 us at 8 clips per call)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)H * W * C4) return;
     {
@@ -357,7 +359,13 @@ template <int TPT, bool NT>      // taps per thread: 3 (one kernel row; blockIdx
 __device__ __forceinline__ unsigned dcn_cols9_body(const DcnColsParams& p)
 {
     const int C4 = p.C / 4;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // blocks are dealt to the eight XCDs round-robin: consecutive blocks of ONE XCD take consecutive pixels, so that the corners the
+    // taps of neighbouring pixels share are fetched into one L2 instead of into all of them (round-5 PMC: 534 MB fetched per launch
+    // for a 134 MB input with pixel groups dealt round-robin; same-box A/B: 365 -> 295-330 us per launch at 8 clips per call, +0.35 % on the step)
+    const int nblk = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const long idx = (long)swz * blockDim.x + threadIdx.x;
     if (idx >= (long)p.Ho * p.Wo * C4) return 0u;
     unsigned rmax = 0u;
     const int c4 = (int)(idx % C4);
