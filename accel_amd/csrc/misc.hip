@@ -987,11 +987,12 @@ __global__ __launch_bounds__(256) void range_fold_kernel(unsigned* slot, unsigne
 {
     __shared__ unsigned sm[4];
     const uint4 v = reinterpret_cast<const uint4*>(slot + RANGE_PART_OFF)[threadIdx.x];      // RANGE_PART = 4 x 256
+    const unsigned w0 = threadIdx.x == 0 ? slot[0] : 0u;      // (requested with the partial words: not a second round trip behind the barrier)
     unsigned m = range_wave_max(max(max(v.x, v.y), max(v.z, v.w)));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = max(max(max(sm[0], sm[1]), max(sm[2], sm[3])), slot[0]);
+        m = max(max(max(sm[0], sm[1]), max(sm[2], sm[3])), w0);
         slot[0] = m;
         if (m >= 0x7F800000u && rflag && atomicCAS(rflag, 0u, (unsigned)op_index + 1u) == 0u) { rflag[1] = m; __threadfence_system(); }
     }
