@@ -108,6 +108,7 @@ def test_clip_f16_close_to_fp32_oracle(demo_cfg, f16_mode):
         assert float((lab != rlab[0]).mean()) < 1e-2
 
 
+@pytest.mark.gpu_extra      # (the f16 mode WITHOUT half storage, a non-default sub-mode; the default is checked at this size in test_f16_storage_gpu.py and at config 5's)
 def test_clip_f16_matches_the_oracle_on_half_rounded_operands_512x1024(demo_cfg, f16_mode, monkeypatch):
     """The reduced-precision mode against ITS OWN specification: oracle.graphs with ROUND_F16 rounds the operands of the
     same layers the HIP loader rounds (Cin % 8 == 0, more than 4 output channels; deformable layers: the sampled columns)

@@ -458,7 +458,8 @@ def test_stale_feature_handle_is_never_read_silently(demo_cfg):
         tester.release_models()
 
 
-@pytest.mark.parametrize("version", ["18", pytest.param("101", marks=pytest.mark.gpu_extra)])
+# (inside `-m gpu` the same statement is made at the headline size: test_configs_gpu.py test_config4_batch8_1024x2048_equals_eight_single_clip_runs)
+@pytest.mark.parametrize("version", [pytest.param("18", marks=pytest.mark.gpu_extra), pytest.param("101", marks=pytest.mark.gpu_extra)])
 def test_batched_clips_match_single_clip_runs(demo_cfg, version):
     """Throughput mode: every call runs one frame of each of B independent clips (arrays with a leading batch of B).
     Image b of the batched run must reproduce the batch-1 run of clip b (same kernels, other tile choices: compared
