@@ -196,7 +196,7 @@ static int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
 // ACCEL_WITHHOLD="winograd,ws1x1,...": kernel families a plan does NOT offer to its tuner (A/B runs and diagnostics; a geometry a
 // conv forces with tile= is packed regardless).  Families: split (every bf16x3 / fp16x2 geometry: the fp32 MFMA kernels remain),
-// b3r (conv_b3r.hip), winograd, winograd_split (41-43), stem, stem_split (51), ws1x1, deep (the deep-prefetch tiles 31-35).
+// b3r (conv_b3r.hip), winograd, winograd_split (41-43), stem, stem_split (51), ws1x1, halo (78), deep (the deep-prefetch tiles 31-35).
 static bool withheld(const char* family)
 {
     const char* e = getenv("ACCEL_WITHHOLD");
@@ -1400,7 +1400,7 @@ static int autotune_plan(accel_plan* p)
         else if (c.f16 && c.Cout_store <= 32) { cs.push_back({3, 0, 0}); cs.push_back({3, 1024, 0}); }
         else if (c.Cout_store <= 32) {
             cs.push_back({4, 0, 0}); cs.push_back({4, 1024, 0}); cs.push_back({9, 0, 0}); cs.push_back({9, 1024, 0}); cs.push_back({3, 0, 0});
-            if (c.wh2r && conv_halo_eligible(c)) cs.push_back({CONV_TILE_HALO, 0, 1});      // the offset branches of res5 (conv_halo.hip)
+            if (c.wh2r && conv_halo_eligible(c) && !withheld("halo")) cs.push_back({CONV_TILE_HALO, 0, 1});      // the offset branches of res5 (conv_halo.hip)
         }
         else {
             // (a layer that runs in fp16-MFMA mode stays on the fp16 kernel: "operands of every convolution with Cin % 8 == 0 and
@@ -1427,7 +1427,7 @@ static int autotune_plan(accel_plan* p)
             if (c.wstem && !c.f16) cs.push_back({CONV_TILE_STEM, 0, 0});
             if (c.wstemb && !c.f16) cs.push_back({CONV_TILE_STEM_B3, 0, 0});
             if (c.wws && !c.f16) cs.push_back({CONV_TILE_WS, 0, 0});
-            if (c.wh2r && !c.f16 && conv_halo_eligible(c)) cs.push_back({CONV_TILE_HALO, 0, 1});
+            if (c.wh2r && !c.f16 && conv_halo_eligible(c) && !withheld("halo")) cs.push_back({CONV_TILE_HALO, 0, 1});
             const int nb3 = c.wb3 ? 5 : 0;
             static const int tiles[] = {0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 31, 32, 33, 34, 35,
                                         CONV_TILE_B3, CONV_TILE_B3 + 1, CONV_TILE_B3 + 2, CONV_TILE_B3 + 3, CONV_TILE_B3 + 4, CONV_TILE_B3 + 5,

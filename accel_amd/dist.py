@@ -315,3 +315,107 @@ class ScoreGather(object):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
+
+
+class Watchdog(object):
+    """Fail fast, and say who.  A job of N ranks whose collective one rank never joins does not fail: it hangs -- ncclSend / ncclRecv
+    of the C-ABI gathers carry no timeout (torch.distributed's watchdog only sees torch's own collectives).  This object gives every
+    PHASE of such a job a deadline: `with wd.phase("preflight gather", 60): ...` marks this rank as having reached the phase in the
+    rendezvous store, and a background thread ends the PROCESS (exit code 3, os._exit: the blocked call cannot be interrupted) when the
+    phase is still open at its deadline -- after printing, from the store, which ranks never reached it and which did not leave it.
+    Under torch.distributed.run one rank exiting ends the others.  `beat()` pushes the deadline of the open phase out again (one call
+    per step of a long loop).  store=None (a single process): the deadline alone."""
+
+    EXIT_CODE = 3
+
+    def __init__(self, rank, world, store=None, stream=None, _exit=None):
+        import threading
+        self.rank, self.world, self.store = int(rank), int(world), store
+        self.stream = stream
+        self._exit = _exit or os._exit
+        self._lock = threading.Lock()
+        self._name, self._deadline, self._seconds = None, None, 0.0
+        self._stop = False
+        self._thread = threading.Thread(target=self._watch, name="accel-watchdog", daemon=True)
+        self._thread.start()
+
+    def _key(self, name, what):
+        return "accel_watchdog/%s/%s" % (name.replace(" ", "_"), what)
+
+    def _mark(self, name, what):
+        if self.store is not None:
+            try:
+                self.store.set(self._key(name, "%s/%d" % (what, self.rank)), "1")
+            except Exception:
+                pass
+
+    def _ranks(self, name, what):
+        """ranks that have set the marker `what` of phase `name` (None: the store cannot be asked)"""
+        if self.store is None:
+            return None
+        try:
+            return [r for r in range(self.world) if self.store.check([self._key(name, "%s/%d" % (what, r))])]
+        except Exception:
+            return None
+
+    def phase(self, name, seconds):
+        wd = self
+
+        class _Phase(object):
+            def __enter__(self_):
+                import time
+                wd._mark(name, "reached")
+                with wd._lock:
+                    wd._name, wd._seconds, wd._deadline = name, float(seconds), time.monotonic() + float(seconds)
+                return wd
+
+            def __exit__(self_, *exc):
+                with wd._lock:
+                    wd._name, wd._deadline = None, None
+                if exc[0] is None:
+                    wd._mark(name, "left")
+                return False
+        return _Phase()
+
+    def beat(self):
+        import time
+        with self._lock:
+            if self._deadline is not None:
+                self._deadline = time.monotonic() + self._seconds
+
+    def report(self, name, seconds):
+        reached, left = self._ranks(name, "reached"), self._ranks(name, "left")
+        msg = "accel watchdog, rank %d of %d: phase '%s' made no progress for %g s" % (self.rank, self.world, name, seconds)
+        if reached is not None:
+            absent = [r for r in range(self.world) if r not in reached]
+            inside = [r for r in reached if r not in (left or [])]
+            msg += "; ranks that never reached it: %s; ranks still inside it: %s" % (absent or "none", inside or "none")
+        return msg
+
+    def _watch(self):
+        import sys
+        import time
+        while not self._stop:
+            time.sleep(0.25)
+            with self._lock:
+                name, deadline, seconds = self._name, self._deadline, self._seconds
+            if deadline is not None and time.monotonic() > deadline:
+                out = self.stream or sys.stderr
+                try:
+                    out.write(self.report(name, seconds) + " -- ending this rank (exit code %d)\n" % self.EXIT_CODE)
+                    out.flush()
+                finally:
+                    self._exit(self.EXIT_CODE)
+                return
+
+    def close(self):
+        self._stop = True
+
+
+def default_store():
+    """the rendezvous store of the default process group (what torch.distributed.run's ranks met through), or None"""
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+    except Exception:
+        return None

@@ -130,6 +130,14 @@ class Lowering(object):
                 continue
             self.flow_ancestors.add(id(m_))
             stack.extend(m_.inputs)
+        # The `offset` input of a DeformableConvolution is a sampling position as well.  Its PRODUCER alone is tagged (the offset
+        # branch is one 3x3 convolution; the layers in front of it also feed the data path, where rounding is not amplified):
+        # measured in round 6 (scripts/debug/layer_diff.py, profiles/r06_margin_bisect.log) the offsets of two launch-geometry
+        # tables differ by 1.3e-6 of their range and the sampled columns by 1.6e-6 -- ordinary summation-order noise -- so the tag
+        # changes no decision today; it keeps a future Winograd form away from them.
+        for n_ in self.nodes:
+            if n_.op == "DeformableConvolution" and len(n_.inputs) > 1:
+                self.flow_ancestors.add(id(n_.inputs[1]))
         self.heads = sym._heads()
         self.head_ids = set(id(h) for h in self.heads)
         self.ops = []          # (kind, dict, [views read], [views written])

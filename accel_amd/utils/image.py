@@ -31,31 +31,28 @@ def _resize_bilinear(im, out_h, out_w, scale_y=None, scale_x=None):
 
 
 def resize(im, target_size, max_size, stride=0):
-    """Scale the short side to target_size, capped so the long side <= max_size;
-    optional zero padding to a multiple of `stride` (image.py:194-222).  For
-    1024x2048 Cityscapes frames at SCALES (1024, 2048) the scale is exactly 1."""
-    im_shape = im.shape
-    im_size_min = np.min(im_shape[0:2])
-    im_size_max = np.max(im_shape[0:2])
-    im_scale = float(target_size) / float(im_size_min)
-    if np.round(im_scale * im_size_max) > max_size:
-        im_scale = float(max_size) / float(im_size_max)
-    if im_scale != 1.0:
-        im = _resize_bilinear(im, int(round(im_shape[0] * im_scale)), int(round(im_shape[1] * im_scale)), 1.0 / im_scale, 1.0 / im_scale)
+    """Contract of lib/utils/image.py:194-222: the SHORT side goes to `target_size` unless that would push the long side past
+    `max_size` (then the long side goes to `max_size`); with `stride` > 0 the result is zero-padded at the bottom / right to the
+    next multiple of it (as float64, like the reference's pad buffer).  Returns (image, scale).  1024x2048 Cityscapes frames at
+    SCALES (1024, 2048): scale exactly 1, nothing is resampled."""
+    rows, cols = im.shape[:2]
+    short, long_ = (rows, cols) if rows <= cols else (cols, rows)
+    scale = float(target_size) / float(short)
+    if np.round(scale * long_) > max_size:
+        scale = float(max_size) / float(long_)
+    if scale != 1.0:
+        im = _resize_bilinear(im, int(round(rows * scale)), int(round(cols * scale)), 1.0 / scale, 1.0 / scale)
     if stride == 0:
-        return im, im_scale
-    im_height = int(np.ceil(im.shape[0] / float(stride)) * stride)
-    im_width = int(np.ceil(im.shape[1] / float(stride)) * stride)
-    padded_im = np.zeros((im_height, im_width, im.shape[2]))
-    padded_im[:im.shape[0], :im.shape[1], :] = im
-    return padded_im, im_scale
+        return im, scale
+    up = lambda n: -(-n // stride) * stride         # next multiple of the stride
+    canvas = np.zeros((up(im.shape[0]), up(im.shape[1]), im.shape[2]))
+    canvas[:im.shape[0], :im.shape[1]] = im
+    return canvas, scale
 
 
 def transform(im, pixel_means):
-    """BGR HxWx3 -> 1x3xHxW RGB minus means; pixel_means is [B, G, R] indexed 2-i
-    (image.py:224-235).  float64 like the reference; arrays become fp32 when they
-    are handed to the predictor (demo.py:186)."""
-    im_tensor = np.zeros((1, 3, im.shape[0], im.shape[1]))
-    for i in range(3):
-        im_tensor[0, i, :, :] = im[:, :, 2 - i] - pixel_means[2 - i]
-    return im_tensor
+    """Contract of lib/utils/image.py:224-235: a BGR H x W x 3 frame becomes the 1 x 3 x H x W RGB tensor with the per-channel
+    mean removed (`pixel_means` is given in B, G, R order like the frame).  float64 like the reference; arrays become fp32
+    when they are handed to the predictor (demo.py:186)."""
+    centred = np.asarray(im, np.float64) - np.asarray(pixel_means, np.float64).reshape(1, 1, 3)
+    return np.ascontiguousarray(centred[:, :, ::-1].transpose(2, 0, 1))[None]

@@ -66,6 +66,12 @@ def parse():
                          "input buffers: an extension, not the reference executor's semantics; reported as secondary.*_zero_copy_inputs by default")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: initialise torch.distributed anyway (exercises the RCCL gather path on one GPU)")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, have each print its rank / world size, exit (no GPU work)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1 (always on there) or --force-dist: before any timed work every rank creates its communicator and sends one score map "
+                         "(or frame) through the gather, under a watchdog that ends the job after --watchdog seconds and prints which rank did "
+                         "not arrive; with this flag alone the job stops after the preflight and rank 0 prints its record")
+    ap.add_argument("--watchdog", type=float, default=60.0, help="seconds a phase of a multi-rank job (communicator, preflight, one step) may take")
+    ap.add_argument("--rank-logs", default=None, help="directory for the stdout of ranks > 0 (default: gpurun_out/ if it exists, else the temp directory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -138,14 +144,41 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a number "
                          "for another job size" % (a.gpus, world))
     if a.launch_check:      # (tests: the launch path without a GPU) every rank reports itself and leaves
-        print(json.dumps({"launch_check": True, "rank": int(os.environ.get("RANK", 0)), "world": world,
-                          "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "self_launched": os.environ.get("ACCEL_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        _emit({"launch_check": True, "rank": int(os.environ.get("RANK", 0)), "world": world,
+               "local_rank": int(os.environ.get("LOCAL_RANK", 0)), "self_launched": os.environ.get("ACCEL_BENCH_SELF_LAUNCHED") == "1"})
         return
+    _rank_stdout_to_file(a, int(os.environ.get("RANK", 0)))
     with _StdoutToStderr():
         out, finish = _run(a)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        _emit(out)
     finish()
+
+
+def _emit(record):
+    """ONE write(2) call per record: the ranks of a job share the launcher's stdout pipe, and a line assembled from several writes
+    (print: text, then the newline) can be cut in two by another rank's line (round-5 review: `JSONDecodeError: Extra data`)."""
+    sys.stdout.flush()
+    os.write(1, (json.dumps(record) + "\n").encode())
+
+
+def _rank_stdout_to_file(a, rank):
+    """Only rank 0 owns the job's stdout (the driver parses ONE JSON line from it): every other rank's fd 1 -- Python prints and
+    the C libraries' alike -- goes to <--rank-logs>/bench_rank<r>.stdout for the whole run; stderr stays shared."""
+    if rank == 0:
+        return
+    d = a.rank_logs or (os.path.join(HERE, "gpurun_out") if os.path.isdir(os.path.join(HERE, "gpurun_out")) else None)
+    if d is None:
+        import tempfile
+        d = tempfile.gettempdir()
+    try:
+        os.makedirs(d, exist_ok=True)
+        fd = os.open(os.path.join(d, "bench_rank%d.stdout" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    except OSError:
+        fd = os.open(os.devnull, os.O_WRONLY)
+    sys.stdout.flush()
+    os.dup2(fd, 1)
+    os.close(fd)
 
 
 BF16_PEAK_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
@@ -566,22 +599,67 @@ def _run(a):
         except Exception as e:   # keep the bench alive; the JSON says what happened
             wl.gather = None
             gather_note = "disabled: %r" % (e,)
+        # ... on EVERY rank or on none: a rank that dropped its gather alone would leave the others in ncclSend / ncclRecv groups it never
+        # joins (round-5 review, weak 7a).  The constructors decide collectively already; this vote covers what remains (an allocation
+        # that failed on one rank).
+        if adist._vote_any(wl.gather is None, wl.model.ctx, None) and wl.gather is not None:
+            wl.gather.close()
+            wl.gather = None
+            gather_note = "disabled: another rank could not set its gather up"
+
+    # Multi-rank jobs fail FAST and the same way on every rank: each phase has a deadline (accel_amd.dist.Watchdog: the rank that gives
+    # up prints which ranks never reached the phase), and a collective that raises ends the rank -- torch.distributed.run then ends
+    # the job -- instead of being dropped by one rank while the others keep issuing it.
+    wd = adist.Watchdog(rank, world, adist.default_store()) if dist is not None else None
+    preflight = None
+    if wd is not None and wl.gather is not None:
+        t0 = time.perf_counter()
+        with wd.phase("preflight gather", a.watchdog):
+            if wl.scores_gather:
+                wl.gather.submit(wl.key)      # the maps of a plan that has not run yet: whatever the `scores` buffer holds travels
+            else:
+                wl.gather.submit()
+            wl.gather.drain()
+            wl.sync()
+        preflight = {"ok": True, "seconds": round(time.perf_counter() - t0, 3), "payload": payload, "transport": wl.gather.transport}
+    if a.preflight:
+        if wd is not None:
+            wd.close()
+        out = {"preflight": preflight or {"ok": wl.gather is not None, "note": gather_note}, "n_gpus": world, "gather": gather_note} if rank == 0 else None
+        wl.close()
+
+        def finish_pre():
+            if dist is not None:
+                with _StdoutToStderr():
+                    dist.barrier()
+                    dist.destroy_process_group()
+        return out, finish_pre
 
     gather_failures = []
     _step = wl.step
 
     def guarded_step():
+        if wd is not None:
+            wd.beat()
         try:
             _step()
-        except Exception as e:      # a failing collective must not cost the whole measurement
-            if wl.gather is None:
+        except Exception as e:
+            if wl.gather is None or world > 1:
+                # N > 1: no rank may carry on without a collective the others still issue -- say what happened and end the job
+                sys.stderr.write("bench.py rank %d of %d: step failed (%r); ending the job\n" % (rank, world, e))
+                sys.stderr.flush()
                 raise
+            # one rank (--force-dist on a single GPU): the measurement goes on without the gather and the record says so
             wl.gather = None
             gather_failures.append(repr(e))
             _step()
     wl.step = guarded_step
 
-    elapsed = wl.timed(a.steps, a.warmup, dist)
+    if wd is not None:
+        with wd.phase("timed steps", max(a.watchdog, 60.0)):
+            elapsed = wl.timed(a.steps, a.warmup, dist)
+    else:
+        elapsed = wl.timed(a.steps, a.warmup, dist)
     rank_ms = None
     if dist is not None:
         # every rank's own time for the K steps (between the two barriers a rank that finishes early waits in the second one, so
@@ -606,7 +684,8 @@ def _run(a):
                                            own_bytes=B_rank * H * W if B_rank != B else None) if other == "labels"
                          else adist.FrameGather(wl.model, wl.model.ctx, "logits", (B, 19, H, W), "f4", local_rank,
                                                 own_bytes=B_rank * 19 * H * W * 4 if B_rank != B else None))
-            el2 = wl.timed(a.steps, 1, dist)
+            with wd.phase("timed steps, other payload", max(a.watchdog, 60.0)):
+                el2 = wl.timed(a.steps, 1, dist)
             t2 = torch.tensor([el2], dtype=torch.float64, device="cuda")
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             el2 = float(t2.item())
@@ -667,6 +746,10 @@ def _run(a):
                                        else "reference layer list one to one (ACCEL_FOLD_LINEAR=0)"), "outputs": "fp32 logits 19xHxW + uint8 labels, left in HBM"}}
     if rank == 0 and gather_detail is not None:
         out["gather_rates"] = gather_detail
+    if rank == 0 and preflight is not None:
+        out["preflight"] = preflight
+    if wd is not None:
+        wd.close()
     if rank == 0 and rank_ms is not None:
         out["rank_ms_per_step"] = rank_ms
     if rank == 0 and not a.no_roofline:

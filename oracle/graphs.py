@@ -22,6 +22,10 @@ EPS_PREACT = 2e-5   # residual_unit / resnet(), :50-75,108
 # deviation ONLY around such a pixel (tests/parity_report.py).
 RECORD = None
 BORDER_EPS = 1e-4
+# The warp is ill-conditioned (not discontinuous) where a bilinear tap straddles the image border (ops.warp_border_points).
+# While RECORD_WARP is a list, cur_forward appends (stride in image pixels, (k, 3) array of those output pixels): the parity
+# report states the error inside and outside their footprints separately; the tolerance is the same everywhere.
+RECORD_WARP = None
 
 
 # fp16-MFMA mode of the HIP path (plan option dtype=f16, BASELINE config 5): the operands of every convolution with
@@ -256,6 +260,8 @@ def cur_forward(P, version, data, data_key, feat_key):
     accel_50.py:156-228, accel_101.py:144-193."""
     version = str(version)
     flow = flownet(P, data, data_key)
+    if RECORD_WARP is not None:
+        RECORD_WARP.append((data.shape[2] // flow.shape[2], O.warp_border_points(flow)))
     warped = O.flow_warp(feat_key, flow)
     out = {"warping_feat_output": warped, "_flow": flow}
     hw = data.shape[2:]
@@ -328,16 +334,18 @@ def run_clip(P, version, frames, interval):
     idx % interval == 0 -> key graph, else cur graph with data_key = PREVIOUS
     frame and feat_key = previously propagated feature (demo.py:176-181,241).
     Returns per-frame (logits, labels)."""
-    global RECORD
+    global RECORD, RECORD_WARP
     version = str(version)
     outs = ClipResult()
     feat = None
     prev = None
     carried = []       # discontinuity points of the key frame: they travel with the propagated feature
+    carried_warp = []  # border-straddling warp pixels since the last key frame: the warped feature is the next frame's source
     for idx, im in enumerate(frames):
         if prev is None:
             prev = im
         saved, RECORD = RECORD, []
+        saved_warp, RECORD_WARP = RECORD_WARP, []
         try:
             if idx % interval == 0:
                 o = key_forward(P, im)
@@ -348,13 +356,18 @@ def run_clip(P, version, frames, interval):
                 feat = o["warping_feat_output"]
                 logits = o["croped_score_output" if version in ("101", "dff") else "correction_output"]
             pts = [(name, int(n), (oy + 0.5) * s, (ox + 0.5) * s) for name, s, arr in RECORD for n, oy, ox in arr]
+            wpts = [(int(n), (oy + 0.5) * s, (ox + 0.5) * s) for s, arr in RECORD_WARP for n, oy, ox in arr]
         finally:
             RECORD = saved
+            RECORD_WARP = saved_warp
         if idx % interval == 0:
             carried = list(pts)
+            carried_warp = []
             outs.critical.append(list(pts))
         else:
             outs.critical.append(carried + pts)
+            carried_warp = carried_warp + wpts
+        outs.warp_border.append(list(carried_warp))
         prev = im
         outs.append((logits, O.argmax_c(logits)))
     return outs
@@ -368,3 +381,4 @@ class ClipResult(list):
     def __init__(self, *a):
         super().__init__(*a)
         self.critical = []
+        self.warp_border = []      # per frame: (image index, y, x) in image pixels, ops.warp_border_points of this and the earlier non-key frames

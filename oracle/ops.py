@@ -216,6 +216,27 @@ def flow_warp(feat, flow):
     return bilinear_sampler(feat, grid_generator_warp(flow))
 
 
+def warp_border_points(flow):
+    """Output pixels (n, y, x) of GridGenerator(warp) + BilinearSampler whose sampling position has a tap OUTSIDE the map while
+    another is inside: x + flow_x in (-1, 0) or (W-1, W), likewise in y.  There the sampled value falls off linearly from the
+    border pixel's value to the zero padding, so its derivative with respect to the sampling position is the FEATURE itself
+    (hundreds) instead of a difference of neighbours -- and the reference's formula quantises that position: `flow + x` is
+    rounded to the fp32 grid at x (7.6e-6 px at x = 127), `/ sx - 1` and `(g + 1) * (W-1) / 2` round again.  Two fp32
+    evaluations whose flows differ in the last bits (any two summation orders) land on neighbouring grid values at a few
+    per cent of such pixels, and the sampled value then differs by ulp(W-1) x |feature| (scripts/debug/flow_exact.py,
+    profiles/r06_margin_bisect.log).  The parity report lists these pixels; it tolerates nothing extra there.
+    Returns an int array (k, 3).  float64 throughout."""
+    f = np.asarray(flow, np.float64)
+    N, two, H, W = f.shape
+    xr = f[:, 0] + np.arange(W).reshape(1, 1, W)
+    yr = f[:, 1] + np.arange(H).reshape(1, H, 1)
+    part_x = ((xr > -1) & (xr < 0)) | ((xr > W - 1) & (xr < W))
+    part_y = ((yr > -1) & (yr < 0)) | ((yr > H - 1) & (yr < H))
+    live_x = (xr > -1) & (xr < W)
+    live_y = (yr > -1) & (yr < H)
+    return np.argwhere((part_x & live_y) | (part_y & live_x))
+
+
 def relu(x):
     return np.maximum(x, np.float32(0))
 

@@ -78,12 +78,35 @@ def logit_tolerance(ref_logits, abs_tol=1e-3, rel_tol=0.0):
     return max(abs_tol, rel_tol * float(np.abs(ref_logits).max()))
 
 
-def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=0.0, max_mismatch=1e-3, max_windows=2, min_classes=2):
+WARP_RADIUS = 40     # image pixels (Chebyshev) around the centre of a stride-16 feature pixel: its 32x32 / 16 upsampling footprint
+
+
+def warp_border_mask(shape, points, image=0, radius=WARP_RADIUS):
+    """H x W mask of the footprints of the border-straddling warp pixels `points` = [(image index, y, x)] (ClipResult.warp_border)"""
+    m = np.zeros(shape, bool)
+    for n, y, x in points or []:
+        if n != image:
+            continue
+        y0, y1 = int(max(0, y - radius)), int(min(shape[0], y + radius + 1))
+        x0, x1 = int(max(0, x - radius)), int(min(shape[1], x + radius + 1))
+        m[y0:y1, x0:x1] = True
+    return m
+
+
+def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=0.0, max_mismatch=1e-3, max_windows=2, min_classes=2, margin_bar=None):
+    """margin_bar (BASELINE configs: 0.7): the error OUTSIDE the footprints of the oracle's border-straddling warp pixels must stay
+    below margin_bar x tolerance -- inside them two fp32 evaluations of the reference's own sampling formula differ by
+    ulp(W - 1) x |feature| wherever their flows round to neighbouring grid values (oracle.ops.warp_border_points), which is
+    what the largest errors of every non-key frame are; the flat tolerance holds there as everywhere.  A frame whose overall
+    error exceeds 0.7 x tolerance is reported with a WARNING line either way."""
     lines = []
     crit_all = getattr(ref, "critical", None)
+    warp_all = getattr(ref, "warp_border", None)
     for t, ((lg, lab), (rlg, rlab)) in enumerate(zip(outs, ref)):
         tol = logit_tolerance(rlg, abs_tol, rel_tol)
         emap = np.abs(lg - rlg).max(axis=(0, 1))
+        wpts = warp_all[t] if warp_all is not None and t < len(warp_all) else []
+        wmask = warp_border_mask(emap.shape, wpts)
         crit = None
         if crit_all is not None:
             crit = crit_all[t]
@@ -105,7 +128,19 @@ def check_against_oracle(outs, ref, tag, abs_tol=1e-3, rel_tol=0.0, max_mismatch
         lines.append("%s frame %d: max|logit err| e=%.3g (tol %.3g, |logit|max %.3g, %d classes in the label map, %d border-tap points); pixels / label "
                      "mismatches per oracle top-2 margin bin: %s" % (tag, t, err, tol, float(np.abs(rlg).max()), len(np.unique(rlab)), len(crit or []),
                                                                     "  ".join("%s %d/%d" % (n, c, m) for n, c, m in rows)))
+        emap_kept = np.abs(lg - rlg).max(axis=(0, 1))
+        e_out = float(emap_kept[~wmask].max()) if not wmask.all() else 0.0
+        e_in = float(emap_kept[wmask].max()) if wmask.any() else 0.0
+        lines.append("%s frame %d: %d border-straddling warp pixel(s), their footprints cover %.2f %% of the frame: max|logit err| inside %.3g, "
+                     "OUTSIDE %.3g" % (tag, t, len(wpts), 100.0 * float(wmask.mean()), e_in, e_out))
+        if err > 0.7 * tol:
+            y, x = np.unravel_index(int(np.argmax(emap_kept)), emap_kept.shape)
+            lines.append("WARNING %s frame %d: e = %.3g is above 0.7 x tolerance; the peak at pixel (%d, %d) lies %s the footprint of a "
+                         "border-straddling warp pixel" % (tag, t, err, y, x, "INSIDE" if wmask[y, x] else "OUTSIDE"))
         assert err <= tol, "%s frame %d: logits err %g > %g" % (tag, t, err, tol)
+        if margin_bar is not None:
+            assert e_out <= margin_bar * tol, ("%s frame %d: logits err %g outside the warp-border footprints exceeds %g x the tolerance"
+                                               % (tag, t, e_out, margin_bar))
         safe = margin > 2 * err
         np.testing.assert_array_equal(lab[safe], rlab[safe], err_msg="%s frame %d: label differs outside the measured rounding band" % (tag, t))
         assert float((lab != rlab).mean()) < max_mismatch, "%s frame %d: %g of the labels differ" % (tag, t, float((lab != rlab).mean()))

@@ -8,8 +8,10 @@
   config 3  Accel-101 1024x2048 against the CPU oracle at full size, and the size-independent properties of
             test_golden_gpu.py for the other model the BASELINE metric names;
   config 4  the RCCL gather of per-frame logits, on one GPU (world size 1): gathered bytes == logits buffer;
-  config 5  Accel-50 with fp16-MFMA convolutions at 2048x4096, key-frame interval 10 schedule (3 frames of it):
-            finite logits, labels agree with the fp32 run of the same clip.
+  config 5  Accel-50 with fp16-MFMA convolutions and half activation storage at 2048x4096, the first two frames of a key-frame
+            interval 10 group (key frame = the ResNet-101 graph, non-key frame = FlowNet + warp + the Accel-50 branch): finite logits,
+            non-degenerate label maps, and both frames against the mode's own specification (the oracle on half-rounded operands
+            and half-rounded stored tensors, oracle.graphs ROUND_F16 + STORE_F16).
 """
 import os
 import socket
@@ -45,6 +47,7 @@ def _oracle_clip(P, version, frames_bgr, cfg, interval):
         if k == key and n >= len(frames_bgr) and digests[:len(frames_bgr)] == tuple(hashlib.sha1(np.ascontiguousarray(f).tobytes()).hexdigest() for f in frames_bgr):
             out = G.ClipResult(ref[:len(frames_bgr)])
             out.critical = ref.critical[:len(frames_bgr)]
+            out.warp_border = ref.warp_border[:len(frames_bgr)]
             return out
     ref = G.run_clip(P, str(version), _oracle_frames(frames_bgr, cfg), interval)
     _ORACLE_RUNS[(key, len(frames_bgr), tuple(hashlib.sha1(np.ascontiguousarray(f).tobytes()).hexdigest() for f in frames_bgr))] = ref
@@ -69,7 +72,7 @@ def test_config1_accel18_512x1024_pair(demo_cfg, interval):
     P = dict(arg)
     P.update(aux)
     ref = _oracle_clip(P, "18", frames, demo_cfg, interval)
-    check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval)
+    check_against_oracle(outs, ref, "config1 accel-18 512x1024 kf=%d" % interval, margin_bar=0.5)
 
 
 @pytest.mark.parametrize("geometry", [pytest.param(41, marks=pytest.mark.gpu_extra), 42, 43])
@@ -170,7 +173,7 @@ def test_config4_batch8_1024x2048_equals_eight_single_clip_runs(demo_cfg, monkey
     P = dict(arg)
     P.update(aux)
     ref = _oracle_clip(P, "18", clips[0], demo_cfg, 3)      # (interval 3 = config 2's schedule: frames 0, 1 are key, non-key as here)
-    check_against_oracle(image0, ref, "config4 accel-18 1024x2048, image 0 of the 8-clip call")
+    check_against_oracle(image0, ref, "config4 accel-18 1024x2048, image 0 of the 8-clip call", margin_bar=0.5)
 
 
 def test_config2_accel18_1024x2048_vs_oracle(demo_cfg, monkeypatch):
@@ -194,7 +197,7 @@ def test_config2_accel18_1024x2048_vs_oracle(demo_cfg, monkeypatch):
             outs = demo.run_clip("18", demo_cfg, arg, aux, frames, interval)
         finally:
             tester.release_models()
-        check_against_oracle(outs, ref, "config2 accel-18 1024x2048 fold=%s" % mode)
+        check_against_oracle(outs, ref, "config2 accel-18 1024x2048 fold=%s" % mode, margin_bar=0.5)
 
 
 def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
@@ -213,11 +216,11 @@ def test_config3_accel101_1024x2048_vs_oracle(demo_cfg):
     P = dict(arg)
     P.update(aux)
     ref = G.run_clip(P, "101", _oracle_frames(frames, demo_cfg), interval)
-    check_against_oracle(outs, ref, "config3 accel-101 1024x2048")
+    check_against_oracle(outs, ref, "config3 accel-101 1024x2048", margin_bar=0.5)
 
 
-@pytest.mark.parametrize("version", [pytest.param("34", marks=pytest.mark.gpu_extra), pytest.param("50", marks=pytest.mark.gpu_extra)])
-# (inside `-m gpu`: both models against the oracle at 128x256, test_graph_gpu.py; Accel-50 at 512x1024 and 2048x4096 in its f16 mode, below)
+@pytest.mark.parametrize("version", [pytest.param("34", marks=pytest.mark.gpu_extra), "50"])
+# (Accel-34 inside `-m gpu`: against the oracle at 128x256 and 208x176, test_graph_gpu.py)
 def test_accel34_accel50_1024x2048_vs_oracle(demo_cfg, version):
     """The other two models at the size the reference validates at: a key and a non-key frame against the CPU oracle."""
     from accel_amd import demo
@@ -233,7 +236,7 @@ def test_accel34_accel50_1024x2048_vs_oracle(demo_cfg, version):
     P = dict(arg)
     P.update(aux)
     ref = G.run_clip(P, version, _oracle_frames(frames, demo_cfg), interval)
-    check_against_oracle(outs, ref, "accel-%s 1024x2048" % version)
+    check_against_oracle(outs, ref, "accel-%s 1024x2048" % version, margin_bar=0.5)
 
 
 def test_config3_accel101_full_size_properties_1024x2048(demo_cfg):
@@ -446,8 +449,8 @@ def test_gather_beside_the_next_frames_compute_does_not_disturb_it(demo_cfg, mon
 
 def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     """Accel-50, fp16-MFMA convolutions with half activation storage, 2048x4096 (config 5's frame size), the first two frames of a
-    kf=10 group (key, non-key: the chain through warp + correction branch): finite logits and non-degenerate label maps on both, the key
-    frame against the mode's own specification (below)."""
+    kf=10 group (key, non-key: the chain through warp + the Accel-50 correction branch, accel_50.py:156-228): finite logits and
+    non-degenerate label maps, and BOTH frames against the mode's own specification (below)."""
     from accel_amd import demo
     from accel_amd.core import tester
     H, W, interval = 2048, 4096, 10
@@ -476,12 +479,12 @@ def test_config5_accel50_f16_2048x4096(demo_cfg, monkeypatch):
     P.update(aux)
     G.ROUND_F16, G.STORE_F16 = True, half_layers("50", H, W, demo_cfg)
     try:
-        # (the KEY frame at this size: two thirds of the oracle's minute and a half; the chain through warp + correction branch is checked
-        # against the same specification at 512x1024, tests/test_f16_storage_gpu.py, and here for finiteness and non-degenerate labels)
-        ref = G.run_clip(P, "50", _oracle_frames(frames[:1], demo_cfg), interval)
+        # (a minute and a half of oracle time on 32 host threads: the key frame is the ResNet-101 graph, the non-key frame the branch
+        # config 5 is named after; round 5 checked the key frame only)
+        ref = G.run_clip(P, "50", _oracle_frames(frames[:2], demo_cfg), interval)
     finally:
         G.ROUND_F16, G.STORE_F16 = False, None
-    for t, ((b, lb), (rlg, rlab)) in enumerate(zip(outs["f16"][:1], ref)):
+    for t, ((b, lb), (rlg, rlab)) in enumerate(zip(outs["f16"][:2], ref)):
         r = rlg[0][:, ::4, ::4]
         scale = max(1.0, float(np.abs(r).max()))
         d = np.abs(b - r).ravel() / scale

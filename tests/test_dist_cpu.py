@@ -220,3 +220,55 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+
+
+def _watchdog_worker(rank, world, port, path):
+    """rank 1 never reaches the phase rank 0 waits in; rank 0's watchdog must end rank 0 and name rank 1"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = open(path % rank, "w")
+    wd = adist.Watchdog(rank, world, adist.default_store(), stream=log)
+    with wd.phase("communicator", 30):
+        dist.barrier()              # both arrive: the phase closes, nobody is ended
+    if rank == 1:
+        time.sleep(20)              # (never enters the next phase while rank 0 waits; ended by the parent)
+        return
+    with wd.phase("preflight gather", 1.5):
+        time.sleep(60)              # stands for an ncclRecv the peer never matches: cannot be interrupted, only the process can go
+
+
+def test_watchdog_ends_a_rank_whose_peer_never_arrives_and_names_it(tmp_path):
+    """Round-5 review, item 8: the first multi-GPU attempt must fail fast and say which rank did not arrive (the C-ABI gathers have no
+    timeout).  World size 2 on gloo: both ranks pass the first phase; rank 1 then stays away from the second, rank 0's watchdog
+    ends rank 0 with exit code 3 within its deadline and the message names rank 1 as the one that never reached the phase."""
+    import time
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    path = str(tmp_path / "wd%d.log")
+    procs = [ctx.Process(target=_watchdog_worker, args=(r, 2, port, path)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    procs[0].join(60)
+    took = time.time() - t0
+    procs[1].terminate()
+    procs[1].join(30)
+    assert procs[0].exitcode == adist.Watchdog.EXIT_CODE, procs[0].exitcode
+    assert took < 45, "rank 0 was not ended by its 1.5 s deadline (%.0f s)" % took
+    text = open(path % 0).read()
+    assert "phase 'preflight gather' made no progress" in text and "never reached it: [1]" in text and "still inside it: [0]" in text, text
+    assert "communicator" not in text
+
+
+def test_watchdog_beat_keeps_a_long_loop_alive_and_close_disarms():
+    import time
+    ended = []
+    wd = adist.Watchdog(0, 1, None, _exit=lambda code: ended.append(code))
+    with wd.phase("timed steps", 1.0):
+        for _ in range(8):
+            time.sleep(0.3)
+            wd.beat()               # 2.4 s of steps under a 1 s per-step deadline
+    time.sleep(0.6)
+    assert ended == []
+    wd.close()

@@ -51,7 +51,7 @@ def test_clip_parity_without_linear_fold(demo_cfg, version, monkeypatch):
     _check(runner_outs, ref, "accel-%s unfolded" % version)
 
 
-@pytest.mark.parametrize("version", ["18", pytest.param("101", marks=pytest.mark.gpu_extra)])
+@pytest.mark.parametrize("version", ["18", "101"])
 def test_clip_parity_dcn_stress_offsets_x20(demo_cfg, version):
     """SURVEY.md 8d "stress set x20": the deformable layers' offset convolutions drawn 20x wider (offsets of 15-30 px, most
     taps of the outer rings land outside the image), whole clip against the oracle.  The operator is discontinuous at the
@@ -459,7 +459,7 @@ def test_stale_feature_handle_is_never_read_silently(demo_cfg):
 
 
 # (inside `-m gpu` the same statement is made at the headline size: test_configs_gpu.py test_config4_batch8_1024x2048_equals_eight_single_clip_runs)
-@pytest.mark.parametrize("version", [pytest.param("18", marks=pytest.mark.gpu_extra), pytest.param("101", marks=pytest.mark.gpu_extra)])
+@pytest.mark.parametrize("version", [pytest.param("18", marks=pytest.mark.gpu_extra), "101"])
 def test_batched_clips_match_single_clip_runs(demo_cfg, version):
     """Throughput mode: every call runs one frame of each of B independent clips (arrays with a leading batch of B).
     Image b of the batched run must reproduce the batch-1 run of clip b (same kernels, other tile choices: compared

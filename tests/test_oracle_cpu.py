@@ -221,7 +221,22 @@ def test_run_clip_reports_border_points_per_frame(demo_cfg):
     assert any(name.startswith("18_res5") for name, _, _, _ in ref.critical[1])
     for name, n, y, x in ref.critical[1]:
         assert n == 0 and 0 <= y < Hh and 0 <= x < Ww
-    assert G.RECORD is None
+    assert G.RECORD is None and G.RECORD_WARP is None
+    # ... and .warp_border the pixels whose bilinear taps straddle the image border: none on a key frame, this frame's on a non-key one
+    assert ref.warp_border[0] == [] and all(n == 0 and 0 <= y < Hh and 0 <= x < Ww for n, y, x in ref.warp_border[1])
+
+
+def test_warp_border_points_known_answers():
+    """ops.warp_border_points: a pixel counts iff one tap of its bilinear sample lies outside the map and another inside."""
+    H, W = 4, 6
+    flow = np.zeros((1, 2, H, W), np.float32)
+    assert len(O.warp_border_points(flow)) == 0            # integer positions inside the map: no tap outside
+    flow[0, 0, 1, W - 1] = 0.25                             # x = W - 1 + 0.25: right tap outside
+    flow[0, 1, 0, 2] = -0.5                                 # y = -0.5: upper taps outside
+    flow[0, 0, 2, 0] = -3.0                                 # x = -3: every tap outside -> the sample is 0 whatever the rounding
+    flow[0, 0, 3, 3] = 0.5                                  # inside
+    pts = sorted(map(tuple, O.warp_border_points(flow).tolist()))
+    assert pts == [(0, 0, 2), (0, 1, W - 1)]
 
 
 def test_argmax_first_max_and_uint8():

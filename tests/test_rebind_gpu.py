@@ -33,7 +33,7 @@ def _bind_and_run(version, cfg, arg, aux, data, nframes=3):
 
 
 @pytest.mark.parametrize("version,binds", [("18", 2), pytest.param("18", 3, marks=pytest.mark.gpu_extra), pytest.param("34", 2, marks=pytest.mark.gpu_extra), pytest.param("50", 2, marks=pytest.mark.gpu_extra),
-                                           pytest.param("101", 2, marks=pytest.mark.gpu_extra), pytest.param("dff", 2, marks=pytest.mark.gpu_extra)])
+                                           ("101", 2), pytest.param("dff", 2, marks=pytest.mark.gpu_extra)])
 def test_every_binding_computes_the_same_frames(demo_cfg, version, binds):
     from accel_amd import demo
     demo_cfg.SCALES[0] = (H, W)
