@@ -166,8 +166,9 @@ struct accel_plan {
     // fp32 layers on the matrix cores: split = 1 (default) the fp16x2 form (two half terms per operand, three products), 0 the
     // bf16x3 form (three bf16 terms, six products) -- plan option split=b3|h2, ACCEL_SPLIT=b3|h2.  The fp16x2 form centres every
     // convolution's pixels in the half range by a power of two that the kernel derives from the RANGE SLOT of its input tensor:
-    // `range` holds n_slots slots of RANGE_WORDS words, zeroed at the start of every run (one memset node of the captured graph) and
-    // raised by the epilogue of whoever writes the tensor -- a run's scales are a function of that run's data, nothing survives it.
+    // `range` holds n_slots slots of RANGE_WORDS words, zeroed at the start of every run (range_clear_kernel, the first node of the
+    // captured graph: a memset node misbehaved, misc.hip) and raised by the epilogue of whoever writes the tensor -- a run's scales are
+    // a function of that run's data, nothing survives it.
     // range_flag: host-mapped word an fp16x2-form convolution raises when its input's range is not finite (ACCEL_ERR_RANGE).
     int split = 1;
     unsigned* range = nullptr;
@@ -182,6 +183,7 @@ struct accel_plan {
     std::map<int, int> slot_of;      // lowering buffer id -> slot index
     std::vector<int> in_slot;        // per op: the slot a convolution with an fp16x2 form reads (-1: none)
     unsigned* range_flag = nullptr;       // host-mapped
+    unsigned* check_scratch = nullptr;    // ACCEL_CHECK_FINITE: one more slot behind the table
     unsigned* range_flag_dev = nullptr;
     int n_h2 = 0;
     size_t ws_bytes = 0;            // split-K workspace shared by the convs of the plan (stream-ordered)
@@ -1126,10 +1128,9 @@ static int run_eager(accel_plan* p)
         // non-finite value is named on stderr
         static const char* chk = getenv("ACCEL_CHECK_FINITE");
         if (chk && chk[0] == '1' && !p->gexec && (op.kind == OP_CONV || op.kind == OP_POOL || op.kind == OP_PREP_RGB) && p->n_slots) {
-            const BufRef& o = op.kind == OP_PREP_RGB ? op.b : op.b;
-            if (o.esize == 4 && o.ptr) {
-                static unsigned* scratch = nullptr;
-                if (!scratch) hipMalloc((void**)&scratch, RANGE_WORDS * sizeof(unsigned));
+            const BufRef& o = op.b;
+            if (o.esize == 4 && o.ptr && p->check_scratch) {      // (one slot of the plan's own allocation: freed with the plan)
+                unsigned* scratch = p->check_scratch;
                 hipStream_t st = p->m->ctx->stream;
                 launch_range_clear(scratch, 1, st);
                 launch_range_amax(o.ptr, (long)o.N * o.H * o.W, roundup(o.C, 4), o.Cs, scratch, st);
@@ -1148,12 +1149,12 @@ static int run_eager(accel_plan* p)
 static int range_check(accel_plan* p)
 {
     if (!p->range_flag || !*p->range_flag) return 0;
-    const unsigned i = *p->range_flag - 1, bits = p->range_flag[1];
+    const unsigned w = *p->range_flag, i = (w & 0x7FFFFFFFu) - 1u;      // one word: (op index + 1) | bit 31 for a NaN (misc.hip range_fold_kernel)
     *p->range_flag = 0u;      // reported once
-    return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s was not finite in an earlier run (largest |value| seen: bit pattern 0x%08x = %s; fp16x2 "
+    return fail(ACCEL_ERR_RANGE, "plan '%s': the input of conv %s was not finite in an earlier run (the largest |value| stored into it was %s; fp16x2 "
                 "form of the fp32 layers: the frames of that run are not trustworthy; ACCEL_SPLIT=b3 selects the bf16x3 form, which propagates "
                 "non-finite values like fp32 arithmetic)",
-                p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", bits, bits == 0x7F800000u ? "infinity" : "NaN");
+                p->role.c_str(), i < p->ops.size() ? p->ops[i].name.c_str() : "?", (w & 0x80000000u) ? "a NaN" : "an infinity");
 }
 
 // Range slots (kernels.h, range.h): which tensors need one, who raises it, who has to measure for himself.
@@ -1191,10 +1192,11 @@ static int assign_range_slots(accel_plan* p)
     }
     p->n_slots = n;
     if (!n) return 0;
-    HIP_TRY(hipMalloc((void**)&p->range, (size_t)n * RANGE_WORDS * sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&p->range, (size_t)(n + 1) * RANGE_WORDS * sizeof(unsigned)));      // (+ 1: the scratch slot of ACCEL_CHECK_FINITE)
     p->owned.push_back(p->range);
-    HIP_TRY(hipMemset(p->range, 0, (size_t)n * RANGE_WORDS * sizeof(unsigned)));
-    HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0] first offender's op index + 1, [1] the range it saw
+    HIP_TRY(hipMemset(p->range, 0, (size_t)(n + 1) * RANGE_WORDS * sizeof(unsigned)));
+    p->check_scratch = p->range + (size_t)n * RANGE_WORDS;
+    HIP_TRY(hipHostMalloc((void**)&p->range_flag, 2 * sizeof(unsigned), hipHostMallocMapped));      // [0]: (first offender's op index + 1) | bit 31 for a NaN
     p->range_flag[0] = p->range_flag[1] = 0u;
     HIP_TRY(hipHostGetDevicePointer((void**)&p->range_flag_dev, p->range_flag, 0));
     for (size_t i = 0; i < p->ops.size(); ++i)
@@ -1829,7 +1831,7 @@ extern "C" int accel_plan_op_range(accel_plan* p, int i, float* scale, int* meas
     return 0;
 }
 
-// diagnostics: the RANGE_WORDS words of conv op i's input slot (word 0 = what the convolution read, words RANGE_PART_OFF.. = the partial words)
+// diagnostics (scripts/debug/range_nan.py; declared in include/accel_hip.h): the RANGE_WORDS words of conv op i's input slot (word 0 = what the convolution read, words RANGE_PART_OFF.. = the partial words)
 extern "C" int accel_plan_op_range_words(accel_plan* p, int i, unsigned* words, int n_words)
 {
     if (!p || !p->finalized || i < 0 || i >= (int)p->ops.size() || !words || n_words < RANGE_WORDS) return fail(ACCEL_ERR_ARG, "accel_plan_op_range_words: bad argument");

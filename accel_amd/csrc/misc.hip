@@ -982,7 +982,8 @@ hipError_t launch_range_clear(unsigned* table, int n_slots, hipStream_t st)
 }
 
 // word 0 of a slot = the maximum of its partial words (and of what word 0 held): one block, in front of the first reader after a write.
-// A non-finite maximum is reported here, once: the host-mapped flag gets the reader's op index + 1 and what was seen (ACCEL_ERR_RANGE).
+// A non-finite maximum is reported here, once, through the host-mapped flag: ONE word -- (the reader's op index + 1) | bit 31 for a NaN --
+// so that the host, which reads it without a stream wait at the start of the next run, never sees half a report (ACCEL_ERR_RANGE).
 __global__ __launch_bounds__(256) void range_fold_kernel(unsigned* slot, unsigned* rflag, int op_index)
 {
     __shared__ unsigned sm[4];
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(256) void range_fold_kernel(unsigned* slot, unsigne
     if (threadIdx.x == 0) {
         m = max(max(max(sm[0], sm[1]), max(sm[2], sm[3])), w0);
         slot[0] = m;
-        if (m >= 0x7F800000u && rflag && atomicCAS(rflag, 0u, (unsigned)op_index + 1u) == 0u) { rflag[1] = m; __threadfence_system(); }
+        if (m >= 0x7F800000u && rflag) { atomicCAS(rflag, 0u, ((unsigned)op_index + 1u) | (m > 0x7F800000u ? 0x80000000u : 0u)); __threadfence_system(); }
     }
 }
 

@@ -54,6 +54,7 @@ def _declare(lib):
         "accel_plan_op_launch": [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_op_mode": [vp, c.c_int, c.POINTER(c.c_int)],
         "accel_plan_op_range": [vp, c.c_int, c.POINTER(c.c_float), c.POINTER(c.c_int)],
+        "accel_plan_op_range_words": [vp, c.c_int, vp, c.c_int],
         "accel_tune_stats": [c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "accel_plan_finalize": [vp],
         "accel_plan_run": [vp],

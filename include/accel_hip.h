@@ -96,9 +96,17 @@ int accel_plan_op_mode(accel_plan* p, int i, int* mode);
  * that wrote the tensor, 2 = measured by a pass over the op's input view (tensors written outside the plan).  The scale is derived by
  * the convolution itself, in its prologue, from the largest |value| of its input tensor in THAT run (the largest lands in
  * [2^13, 2^14)): a plan run is a pure function of its inputs and parameters, like an executor forward of the reference
- * (dff_deeplab/core/module.py:1011-1044) -- nothing is calibrated, nothing survives a run.  A convolution that finds the range of its
- * input non-finite makes the NEXT accel_plan_run fail with ACCEL_ERR_RANGE (once).  Diagnostic only. */
+ * (dff_deeplab/core/module.py:1011-1044) -- nothing is calibrated, nothing survives a run.  A tensor such a convolution reads whose
+ * largest stored |value| was an INFINITY in some run makes the NEXT accel_plan_run fail with ACCEL_ERR_RANGE (once); so does a NaN in a
+ * tensor written by a byte mover (image converters, pools, warps, the deformable sampler, view copies) or measured by a pass of its
+ * own.  A NaN that a matrix-core convolution produces mid-plan is NOT reported: its range epilogue takes floating-point maxima, which
+ * drop NaNs (csrc/conv_epilogue.h); the NaN itself reaches the outputs through the matrix instructions as in fp32 arithmetic.
+ * Diagnostic only. */
 int accel_plan_op_range(accel_plan* p, int i, float* scale, int* source);
+/* Diagnostic (scripts/debug/range_nan.py): the 1088 words of conv op i's input range slot after the plan's last run -- word 0 = the
+ * largest |value| stored into the tensor, as a bit pattern (what the convolution read), words 64 .. 1087 = the partial words the
+ * writers raised (csrc/range.h).  n_words must be at least 1088. */
+int accel_plan_op_range_words(accel_plan* p, int i, unsigned* words, int n_words);
 /* Launch geometries are REPRODUCIBLE: decisions come from the table shipped beside the library (tune/gfx950.tune, covers
  * the BASELINE workloads) or from the user's table ($ACCEL_TUNE_CACHE, else ~/.cache/accel_amd/gfx950.tune); a shape in
  * neither is timed once and appended to the user's table.  Counters of this process: decisions replayed, decisions

@@ -17,8 +17,6 @@ A = synth.make_clip(H, W, 2, seed=5101)
 pre = lambda fr, f: [(np.float32(f) * image.transform(im, config.network.PIXEL_MEANS)).astype(np.float32) for im in fr]
 seqs = [pre(A, 1.0), pre([np.zeros_like(A[0])] * 2, 1.0), pre(A, 8.0), pre(A, 0.01), pre(A, 1.0), pre(A, 100.0), pre(A, 1e-3)]
 lib = runtime.lib()
-lib.accel_plan_op_range_words.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-lib.accel_plan_op_range_words.restype = ctypes.c_int
 
 
 def scan(plan, lw, tag):

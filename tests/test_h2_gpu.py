@@ -188,6 +188,36 @@ def test_the_producer_epilogue_raises_the_consumers_range(ctx, monkeypatch, grap
         m.close()
 
 
+def test_what_is_reported_when_a_producer_emits_non_finite_values(ctx, monkeypatch):
+    """include/accel_hip.h (accel_plan_op_range), round-5 advisor: an INFINITY a matrix-core convolution writes mid-plan is seen by its
+    consumer's range slot and reported by the next run; a NaN it writes is NOT (the epilogue's floating-point maxima drop NaNs) -- it
+    reaches the outputs through the matrix instructions as in fp32 arithmetic, and no error is raised.  (A NaN in a tensor that is
+    MEASURED -- the case of test_the_scale_follows_every_run... with np.inf -- or written by a byte mover is reported.)"""
+    monkeypatch.setenv("ACCEL_SPLIT", "h2")
+    cin, cmid, cout, H, W = 64, 256, 128, 24, 40
+    w1, w2 = rnd(11, cmid, cin, 1, 1, scale=0.2), rnd(12, cout, cmid, 1, 1, scale=0.05)
+    x = rnd(13, 1, cin, H, W)
+    m, plan = _two_convs(ctx, cin, cmid, cout, H, W, w1, w2, 81)
+    try:
+        m.write("x", x); plan.run()
+        good = m.read("y", (1, cout, H, W)).copy()
+        bad = x.copy(); bad[0, 5, 3, 7] = np.nan             # conv a (fp32 MFMA) turns it into a NaN column of its output
+        m.write("x", bad); plan.run()
+        y = m.read("y", (1, cout, H, W))
+        assert np.isnan(y[0, :, 3, 7]).all() and np.isfinite(np.delete(y.reshape(cout, -1), 3 * W + 7, axis=1)).all()
+        m.write("x", x); plan.run()                             # no ACCEL_ERR_RANGE: the NaN never entered b's range slot
+        assert np.array_equal(m.read("y", (1, cout, H, W)), good)
+        big = x.copy(); big[0, 5, 3, 7] = 3e38                 # a's output overflows to +-inf at that pixel: b's slot holds an infinity
+        m.write("x", big); plan.run()
+        m.write("x", x)
+        with pytest.raises(runtime.AccelError, match="an infinity"):
+            plan.run()
+        plan.run()
+        assert np.array_equal(m.read("y", (1, cout, H, W)), good)
+    finally:
+        m.close()
+
+
 def test_split_b3_plan_option_and_env(ctx, monkeypatch):
     """ACCEL_SPLIT=b3 (or plan option split=b3) keeps the bf16x3 form: no range slots, mode 0"""
     monkeypatch.setenv("ACCEL_SPLIT", "b3")
