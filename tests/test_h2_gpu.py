@@ -207,7 +207,7 @@ def test_what_is_reported_when_a_producer_emits_non_finite_values(ctx, monkeypat
         assert np.isnan(y[0, :, 3, 7]).all() and np.isfinite(np.delete(y.reshape(cout, -1), 3 * W + 7, axis=1)).all()
         m.write("x", x); plan.run()                             # no ACCEL_ERR_RANGE: the NaN never entered b's range slot
         assert np.array_equal(m.read("y", (1, cout, H, W)), good)
-        big = x.copy(); big[0, 5, 3, 7] = 3e38                 # a's output overflows to +-inf at that pixel: b's slot holds an infinity
+        big = x.copy(); big[0, 5, 3, 7] = np.inf               # a's output is +inf / 0 (ReLU) at that pixel: b's slot holds an infinity
         m.write("x", big); plan.run()
         m.write("x", x)
         with pytest.raises(runtime.AccelError, match="an infinity"):
