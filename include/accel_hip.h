@@ -100,7 +100,8 @@ int accel_plan_op_mode(accel_plan* p, int i, int* mode);
  * largest stored |value| was an INFINITY in some run makes the NEXT accel_plan_run fail with ACCEL_ERR_RANGE (once); so does a NaN in a
  * tensor written by a byte mover (image converters, pools, warps, the deformable sampler, view copies) or measured by a pass of its
  * own.  A NaN that a matrix-core convolution produces mid-plan is NOT reported: its range epilogue takes floating-point maxima, which
- * drop NaNs (csrc/conv_epilogue.h); the NaN itself reaches the outputs through the matrix instructions as in fp32 arithmetic.
+ * drop NaNs (csrc/conv_epilogue.h); behind a ReLU the NaN itself becomes 0 (fmaxf -- the reference's relu `a > 0 ? a : 0` does the
+ * same), without one it reaches the outputs through the matrix instructions as in fp32 arithmetic.
  * Diagnostic only. */
 int accel_plan_op_range(accel_plan* p, int i, float* scale, int* source);
 /* Diagnostic (scripts/debug/range_nan.py): the 1088 words of conv op i's input range slot after the plan's last run -- word 0 = the
