@@ -1172,7 +1172,7 @@ static bool conv_runs_h2(const ConvParams& c)
     if (c.f16 || c.narrow) return false;
     const int t = c.force_tile;
     return ((t == CONV_TILE_WINO_B3 || t == CONV_TILE_WINO_B3U || t == CONV_TILE_WINO_B3S) && c.wubh) || (t == CONV_TILE_STEM_B3 && c.wstemh) ||
-           (t >= CONV_TILE_B3R && t < CONV_TILE_B3R + 6 && c.wh2r);
+           (((t >= CONV_TILE_B3R && t < CONV_TILE_B3R + 6) || (t >= 90 && t <= 96)) && c.wh2r);      // (90-96: the ablation builds of geometry 76, diagnostics library only)
 }
 
 static int assign_range_slots(accel_plan* p)

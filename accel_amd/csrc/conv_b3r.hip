@@ -278,6 +278,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 8 && BM * BN <= 128 *
         if constexpr ((ABL & 16) == 0) __syncthreads();
     }
 #undef B3R_FENCE_N
+    if constexpr ((ABL & 32) != 0) {      // timing ablation: no epilogue (the accumulators are consumed, one dummy store that never happens)
+        f32x16 t = acc[0][0];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) t += acc[i][j];
+        if (p.slope == 12345.f)
+            for (int e = 0; e < 16; ++e) p.y[threadIdx.x * 16 + e] = t[e];
+        return;
+    }
     conv_epilogue<MI, NI, WGN>(p, acc, m0, n0, wm, wn, lane, py, px, HoWo, rs.inv);
 }
 
@@ -319,6 +329,16 @@ hipError_t launch_conv_b3r(const ConvParams& p, int tile, hipStream_t st)
             case CONV_TILE_B3R + 3: return launch_b3r<128, 256, 2, 4, 0, 2>(p, st);
             case CONV_TILE_B3R + 4: return launch_b3r<128, 256, 1, 8, 0, 2>(p, st);
             case CONV_TILE_B3R + 5: return launch_b3r<128, 128, 1, 4, 0, 2>(p, st);
+#ifdef ACCEL_CONV_DIAG
+            // timing-only ablations of geometry 76 in the fp16x2 form (WRONG results by design; diagnostics build only)
+            case 90: return launch_b3r<128, 128, 2, 4, 1, 2>(p, st);      // no MFMAs
+            case 91: return launch_b3r<128, 128, 2, 4, 2, 2>(p, st);      // no weight loads
+            case 92: return launch_b3r<128, 128, 2, 4, 4, 2>(p, st);      // no pixel loads
+            case 93: return launch_b3r<128, 128, 2, 4, 8, 2>(p, st);      // no split + LDS stores
+            case 94: return launch_b3r<128, 128, 2, 4, 32, 2>(p, st);     // no epilogue
+            case 95: return launch_b3r<128, 128, 2, 4, 33, 2>(p, st);     // no MFMAs, no epilogue: the loader side alone
+            case 96: return launch_b3r<128, 128, 2, 4, 46, 2>(p, st);     // MFMAs + fragment reads + barrier only, no epilogue
+#endif
             default: return hipErrorInvalidValue;
         }
     }

@@ -1272,7 +1272,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, hipStream_t st)
         q.w = static_cast<const float*>(p.wb3r);
         return launch_conv_b3r(q, p.force_tile, st);
     }
-    if (p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6 && !p.f16 && p.wh2r) {
+    if (((p.force_tile >= CONV_TILE_B3R && p.force_tile < CONV_TILE_B3R + 6) || (p.force_tile >= 90 && p.force_tile <= 96)) && !p.f16 && p.wh2r) {      // (90-96: ablations, diagnostics build)
         // the fp16x2 form of the same staging: two half planes per operand, three products
         ConvParams q = p;
         q.w = static_cast<const float*>(p.wh2r);
