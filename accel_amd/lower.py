@@ -96,11 +96,12 @@ class View(object):
 
 
 class Lowering(object):
-    def __init__(self, sym, input_shapes, ncls=19, fold_linear=True, feat_slot=None, store_f16=False):
+    def __init__(self, sym, input_shapes, ncls=19, fold_linear=True, feat_slot=None, store_f16=False, fold_fusion=True):
         self.sym = sym
         self.store_f16 = bool(store_f16)      # f16-mode plans: arena buffers between capable convolutions are kept as half
         self.half_bufs = []
         self.fold_linear = bool(fold_linear)
+        self.fold_fusion = bool(fold_linear) and bool(fold_fusion)      # the split of a fusion over Concat(warp, other): fp32-class plans only (lower())
         # Ping-pong of the propagated feature (non-key graphs): a warp cannot run in place, so the plan either warps into
         # scratch and copies back (feat_slot None: two copies of 0.8 GB per call of 8 frames), or exists TWICE: variant 0
         # reads `feat` / `featG` and writes `feat_b` / `featG_b`, variant 1 the other way round, and the host runs the
@@ -110,6 +111,9 @@ class Lowering(object):
         self.feat_dst = None if feat_slot is None else ("feat" if feat_slot == 1 else "feat_b")
         self.derived = {}      # derived parameter name -> ("deconv4x4s2*conv1x1", deconv weight, conv weight)
         self.derived_bufs = {} # derived persistent buffer -> {"from", "w", "cin", "cout", "H", "W"} (see lower_warp)
+        # Feature fusion over Concat(warped feature, other) (Accel-101, accel_101.py:164-169): conv id -> (Concat node, warp node, other);
+        # warp id -> conv; conv id -> view of the warped image of W_left * feat (plan_concats / lower_warp / lower_anchor)
+        self.split_fusion, self.fusion_of_warp, self.fusion_res = {}, {}, {}
         self.shapes = infer_shapes(sym, input_shapes)
         self.nodes = sym.topo()
         # Accuracy budget: the flow field is the one place where fp32 rounding is AMPLIFIED -- a flow error of
@@ -202,14 +206,16 @@ class Lowering(object):
             return None
         return cons[0]
 
-    def _feat_image(self, conv, C, H, W):
-        """The derived persistent buffer featG = W_conv * feat (no bias), kept in step with `feat` by the plans."""
-        _, cin, _, _ = self.shape(conv.inputs[0])
+    def _feat_image(self, conv, C, H, W, name="featG", wname=None, cin=None):
+        """The derived persistent buffer `name` = W * feat (no bias), kept in step with `feat` by the plans: featG = fc6_weight * feat
+        (the task head on the propagated feature), featC = the left half of corr_weight * feat (Accel-101's feature fusion)."""
+        if cin is None:
+            _, cin, _, _ = self.shape(conv.inputs[0])
         if self.feat_slot == 1:
             # the `_b` pair is only ever written by variant-0 plans, feature and image together: never stale
-            return self.pbuf_view("featG_b", C, H, W)
-        v = self.pbuf_view("featG", C, H, W)
-        self.derived_bufs["featG"] = {"from": "feat", "w": conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W, "N": self.N}
+            return self.pbuf_view(name + "_b", C, H, W)
+        v = self.pbuf_view(name, C, H, W)
+        self.derived_bufs[name] = {"from": "feat", "w": wname or conv.inputs[1].name, "cin": cin, "cout": C, "H": H, "W": W, "N": self.N}
         return v
 
     def dest_for(self, node):
@@ -256,6 +262,8 @@ class Lowering(object):
             if all(i.op == "Crop" and i.inputs[0].op == "Deconvolution" and
                    i.inputs[0].attrs["kernel"] == (32, 32) for i in n.inputs):
                 continue    # score concat -> score_tail
+            if self._plan_split_fusion(n):
+                continue
             N, C, H, W = self.shape(n)
             buf = self.new_buf(C, H, W, N=N)
             off = 0
@@ -269,6 +277,34 @@ class Lowering(object):
                 off += ci
             self.val[id(n)] = View(buf, C, 0)
             self.absorbed.add(id(n))
+
+    def _plan_split_fusion(self, cat):
+        """Linear fold (fold_linear): a 1x1 Convolution over Concat(warp(feat_key), other) -- Accel-101's feature fusion `correction`,
+        accel_101.py:164-169 -- is  W_left * warp(F) + W_right * other + b,  and a 1x1 convolution commutes with the warp (lower_warp):
+        W_left * warp(F) = warp(W_left * F).  The non-key plan therefore warps the 2048-channel image featC = W_left * feat (a derived
+        persistent buffer like featG: rebuilt by the one-conv plan `init:featC` when a key frame has replaced `feat`, then carried from
+        frame to frame by the warp itself) and runs the fusion over `other` alone with the warped image as its residual: half the
+        multiply-adds of the reference's layer, no 4096-channel concat buffer, and the propagated feature can ping-pong between its two
+        buffers instead of being copied back.  Same function; the summation order of the contraction changes (two halves)."""
+        if not self.fold_fusion or len(cat.inputs) != 2:
+            return False
+        B, other = cat.inputs
+        cons = self.consumers(cat)
+        if len(cons) != 1 or cons[0].op != "Convolution" or cons[0].inputs[0] is not cat or id(cat) in self.head_ids:
+            return False
+        conv = cons[0]
+        a = conv.attrs
+        if a["kernel"] != (1, 1) or a["stride"] != (1, 1) or a["pad"] != (0, 0) or a["num_group"] != 1 or a["num_filter"] % 4:
+            return False
+        if B.op not in ("BilinearSampler", "Custom") or id(B) not in self.head_ids or len(self.consumers(B)) != 1:
+            return False
+        feat = B.inputs[0]
+        if feat.op != "null" or feat.name != "feat_key" or self.shape(B)[1] % 4:
+            return False
+        self.split_fusion[id(conv)] = (cat, B, other)
+        self.fusion_of_warp[id(B)] = conv
+        self.absorbed.add(id(cat))
+        return True
 
     # ---- image entry points ------------------------------------------------------------
     def image_sources(self, node):
@@ -357,12 +393,18 @@ class Lowering(object):
         elif op == "DeformableConvolution":
             xin = None
         else:
-            xin = self.input_view(x)
+            xin = None if id(A) in self.split_fusion else self.input_view(x)      # (a fused Concat has no buffer: below)
         widx = 2 if op == "DeformableConvolution" else 1
         wname = A.inputs[widx].name
         bias = None if a["no_bias"] else A.inputs[widx + 1].name
 
         cur, bn, mul, res, act, slope = A, None, None, None, 0, 0.1
+        if id(A) in self.split_fusion:      # (_plan_split_fusion) W_right * other + b + warp(W_left * feat)
+            _, Bw, x = self.split_fusion[id(A)]
+            c0, c1 = self.shape(Bw)[1], self.shape(Bw)[1] + self.shape(x)[1]
+            wr = "%s[:,%d:%d]" % (wname, c0, c1)
+            self.derived[wr] = ("cin_slice", wname, "%d:%d" % (c0, c1))
+            wname, xin, res = wr, self.input_view(x), self.fusion_res[id(A)]
         need_crop = mode == "deconv2x" and a["pad"] == (0, 0)
         cropped = False
         chain = []
@@ -639,6 +681,23 @@ class Lowering(object):
         # warped feature (34.4 GFLOP at 1024x2048) becomes a warp of the 1024-channel image featG = W*F that the key
         # plan (or, after a host upload of `feat`, the init:featG plan) left in HBM; the warped image is also the next
         # frame's featG (iterative warping: F_t = warp(F_t-1)  =>  W*F_t = warp(W*F_t-1)).
+        if id(B) in self.fusion_of_warp:
+            # feature fusion over Concat(this warp, other) (_plan_split_fusion): warp the image featC = W_left * feat as well; the fusion
+            # convolution takes it as its residual
+            conv = self.fusion_of_warp[id(B)]
+            wsrc = conv.inputs[1].name
+            wl = "%s[:,0:%d]" % (wsrc, C)
+            self.derived[wl] = ("cin_slice", wsrc, "0:%d" % C)
+            _, Cg, _, _ = self.shape(conv)
+            g_in = self._feat_image(conv, Cg, H, W, name="featC", wname=wl, cin=C)
+            g_out = self.pbuf_view("featC" if self.feat_slot == 1 else "featC_b", Cg, H, W) if pingpong \
+                else View(self.new_buf(Cg, H, W), Cg)
+            self.emit("warp", {"name": B.name + "*" + conv.name, "feat": g_in, "flow": flow, "out": g_out}, [g_in, flow], [g_out],
+                      nbytes=2.0 * 4 * Cg * H * W + 8.0 * H * W)
+            if not pingpong:
+                g_dst = self.pbuf_view("featC", Cg, H, W)
+                self.emit("copy", {"src": g_out, "dst": g_dst}, [g_out], [g_dst], nbytes=8.0 * Cg * H * W)
+            self.fusion_res[id(conv)] = g_out
         heads = [c for c in self.consumers(B) if self._head_on_feature(c, B) is not None]
         if feat.op == "null" and feat.name == "feat_key" and id(B) in self.head_ids \
                 and len(self.consumers(B)) == 1 and len(heads) == 1:
@@ -738,7 +797,7 @@ class Lowering(object):
             if op == "SoftmaxOutput" and id(n) in self.absorbed:
                 continue
             if op == "Convolution" and n.inputs[0].op == "Concat" and n.inputs[0].attrs.get("dim", 1) == 1 \
-                    and id(n.inputs[0]) not in self.val:
+                    and id(n.inputs[0]) not in self.val and id(n) not in self.split_fusion:
                 cat = n.inputs[0]
                 if a_is_1x1(n) and len(cat.inputs) == 2:
                     cons = self.consumers(n)
@@ -910,6 +969,12 @@ def fold_params(derived, params):
     import numpy as np
     out = {}
     for name, (kind, wd_name, wf_name) in derived.items():
+        if kind == "cin_slice":      # input channels [lo, hi) of a convolution weight (the two halves of a fusion over a Concat)
+            w = params[wd_name]
+            w = np.asarray(w.asnumpy() if hasattr(w, "asnumpy") else w, dtype=np.float32)
+            lo, hi = (int(v) for v in wf_name.split(":"))
+            out[name] = np.ascontiguousarray(w[:, lo:hi])
+            continue
         if kind != "deconv4x4s2*conv1x1":
             raise NotImplementedError(kind)
         wd, wf = params[wd_name], params[wf_name]
@@ -943,5 +1008,8 @@ def lower(sym, input_shapes, graph=True, conv_dtype="f32", fold_linear=True, fea
     import os
     if store_f16 is None:
         store_f16 = os.environ.get("ACCEL_F16_STORAGE", "1") != "0"
-    lw = Lowering(sym, input_shapes, fold_linear=fold_linear, feat_slot=feat_slot, store_f16=bool(store_f16) and conv_dtype == "f16").run()
+    # (an f16-mode plan keeps the fusion of Accel-101 as the reference's one layer: the mode's specification rounds the operands of THAT
+    # contraction -- oracle.graphs ROUND_F16 -- and the rebuild plan of a derived buffer runs in the default arithmetic)
+    lw = Lowering(sym, input_shapes, fold_linear=fold_linear, feat_slot=feat_slot, store_f16=bool(store_f16) and conv_dtype == "f16",
+                  fold_fusion=conv_dtype != "f16").run()
     return lw.text(graph=graph, conv_dtype=conv_dtype), lw

@@ -136,8 +136,29 @@ def test_algorithmic_flops_match_the_survey(demo_cfg):
             assert abs(cut - saved - head) < 1e-6 * saved and len(lwf.derived) == 1 and list(lwf.derived_bufs) == ["featG"]
         elif v == "50":
             assert abs(cut - head) < 1e-6 * head and not lwf.derived and list(lwf.derived_bufs) == ["featG"]
-        else:      # Accel-101 fuses features: its fc6 runs on the `correction` output, not on the warped feature
-            assert cut == 0 and not lwf.derived and not lwf.derived_bufs
+        else:      # Accel-101 fuses features (its fc6 runs on the `correction` output): the fusion over Concat(warped, current) keeps its
+            # right half; the left half runs once per key frame (init:featC) and its image is warped (round 6, lower._plan_split_fusion)
+            half = 2.0 * 64 * 128 * 2048 * 2048 / 1e9
+            assert abs(cut - half) < 1e-6 * half and sorted(lwf.derived) == ["corr_weight[:,0:2048]", "corr_weight[:,2048:4096]"]
+            assert list(lwf.derived_bufs) == ["featC"] and lwf.derived_bufs["featC"]["w"] == "corr_weight[:,0:2048]"
+
+
+def test_fusion_over_a_concat_splits_into_its_two_halves_and_commutes_with_the_warp():
+    """lower._plan_split_fusion (Accel-101's `correction`, accel_101.py:164-169) on the oracle's own operators:
+    conv1x1(Concat(warp(F), X), W) + b  ==  warp(conv1x1(F, W[:, :c])) + conv1x1(X, W[:, c:]) + b, with the slices fold_params makes."""
+    from accel_amd import lower
+    from oracle import ops
+    rng = np.random.RandomState(11)
+    c, co, H, W = 8, 12, 6, 9
+    F, X = rng.randn(1, c, H, W).astype(np.float32), rng.randn(1, c, H, W).astype(np.float32)
+    flow = (rng.randn(1, 2, H, W) * 1.5).astype(np.float32)      # some taps leave the map
+    w, b = (rng.randn(co, 2 * c, 1, 1) * 0.3).astype(np.float32), rng.randn(co).astype(np.float32)
+    ref = ops.conv2d(np.concatenate([ops.flow_warp(F, flow), X], axis=1), w, b)
+    d = lower.fold_params({"w[:,0:%d]" % c: ("cin_slice", "w", "0:%d" % c), "w[:,%d:%d]" % (c, 2 * c): ("cin_slice", "w", "%d:%d" % (c, 2 * c))}, {"w": w})
+    wl, wr = d["w[:,0:%d]" % c], d["w[:,%d:%d]" % (c, 2 * c)]
+    assert wl.shape == (co, c, 1, 1) and np.array_equal(np.concatenate([wl, wr], axis=1), w)
+    got = ops.flow_warp(ops.conv2d(F, wl), flow) + ops.conv2d(X, wr, b)
+    assert float(np.abs(got - ref).max()) <= 1e-5 * float(np.abs(ref).max())
 
 
 def test_linear_fold_weight_is_the_composition():
@@ -190,7 +211,7 @@ def test_plan_is_well_formed(demo_cfg, version, key):
     kinds = [k for k, _ in lw.ops]
     assert kinds.count("score_tail") == 1
     if not key:
-        n = 1 if version == "101" else 2     # score-fusion models also warp the W*feat image (featG)
+        n = 2     # beside the feature itself every model warps a linear image of it: featG = fc6_weight * feat, Accel-101 featC = corr_weight[:, :2048] * feat
         assert kinds.count("warp") == n and kinds.count("prep_flow") == 1 and kinds.count("copy") == n
     assert "Concat" not in text and all(k in ("prep_rgb", "prep_flow", "conv", "pool", "warp", "dcn_cols", "score_tail", "copy") for k in kinds)
 
@@ -231,11 +252,24 @@ def test_feature_pingpong_variants(demo_cfg, version):
     assert _plan(version, True, feat_slot=0)[0] == _plan(version, True)[0]
 
 
-def test_feature_pingpong_falls_back_for_feature_fusion(demo_cfg):
-    """Accel-101 warps straight into the Concat in front of its fusion convolution (accel_101.py:161-166): the warped
-    feature is a slice of that buffer, so the plan keeps its one copy-back and the propagated feature stays in `feat`."""
-    _, v0 = _plan("101", False, feat_slot=0)
-    assert [k for k, _ in v0.ops].count("copy") == 1 and v0.outputs["warping_feat_output"].buf.space == "feat"
+def test_feature_pingpong_with_feature_fusion(demo_cfg):
+    """Accel-101 (accel_101.py:161-166).  Lowered layer by layer (fold_linear=False) the warp writes straight into the Concat in front of
+    the fusion convolution -- the warped feature is a slice of that buffer, so the plan keeps its one copy-back and the propagated feature
+    stays in `feat`.  With the fusion split into its halves (the default, round 6: lower._plan_split_fusion) there is no Concat: the
+    feature and the image featC = corr_weight[:, :2048] * feat ping-pong like feat / featG of the score-fusion models."""
+    _, u0 = _plan("101", False, feat_slot=0, fold_linear=False)
+    assert [k for k, _ in u0.ops].count("copy") == 1 and u0.outputs["warping_feat_output"].buf.space == "feat"
+    (t0, v0), (t1, v1) = _plan("101", False, feat_slot=0), _plan("101", False, feat_slot=1)
+    assert [k for k, _ in v0.ops].count("copy") == 0 and [k for k, _ in v0.ops] == [k for k, _ in v1.ops]
+    assert v0.outputs["warping_feat_output"].buf.space == "feat_b" and v1.outputs["warping_feat_output"].buf.space == "feat"
+    warps = lambda t: [dict(x.split("=", 1) for x in l.split()[1:]) for l in t.splitlines() if l.startswith("warp ")]
+    w0, w1 = warps(t0), warps(t1)
+    assert w0[1]["feat"].startswith("featC:") and w0[1]["out"].startswith("featC_b:")
+    assert w1[1]["feat"].startswith("featC_b:") and w1[1]["out"].startswith("featC:")
+    assert re.search(r"^pbuf name=featC bytes=\d+ from=feat$", t0, re.M) and "from=feat_b" not in t0 + t1
+    # the fusion convolution reads the current frame's feature alone, the right half of the weight, and takes the warped image as residual
+    conv = [dict(x.split("=", 1) for x in l.split()[1:]) for l in t0.splitlines() if l.startswith("conv ") and " name=correction " in l][0]
+    assert conv["w"] == "corr_weight[:,2048:4096]" and conv["cin"] == "2048" and conv["res"].startswith("featC_b:") and conv["bias"] == "corr_bias"
 
 
 def test_fusion_of_the_preactivation_units(demo_cfg):
