@@ -168,7 +168,7 @@ class Predictor(object):
                 model.set_param(name, w)
                 done[name] = token
             model._derived_from = done
-        for name, d in lw.derived_bufs.items():      # rebuild plans of the derived persistent buffers (featG = fc6_weight * feat)
+        for name, d in lw.derived_bufs.items():      # rebuild plans of the derived persistent buffers (featG = fc6_weight * feat; Accel-101: featC = corr_weight[:, :2048] * feat)
             if not self._is_key and ("init:" + name) not in model.plans:
                 model.add_plan("init:" + name, _lower.init_plan_text(name, d)).finalize()
         role = "train" if self._is_train else "key" if self._is_key else "cur"      # key / cur: what accel_key_forward / accel_cur_forward look up

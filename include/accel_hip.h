@@ -74,7 +74,8 @@ int accel_plan_finalize(accel_plan* p);   /* repack weights, allocate arena, cap
 /* enqueue one forward (Module.forward, module.py:1011).
  * Derived persistent buffers: a plan line `pbuf name=featG bytes=.. from=feat` declares featG a function of
  * `feat` that the plans keep in step with it (featG = fc6_weight * feat: non-key plans warp it instead of
- * re-running fc6 on the warped feature).  A plan that writes both leaves featG valid; any other write of `feat`
+ * re-running fc6 on the warped feature; Accel-101's plans have featC = corr_weight[:, :2048] * feat, the left half of
+ * the feature fusion, the same way).  A plan that writes both leaves featG valid; any other write of `feat`
  * (accel_model_write, a raw pointer from accel_model_buffer, a plan that writes only `feat`) makes it stale, and
  * the next plan that READS featG first runs the plan registered under the role "init:featG" -- or fails with
  * ACCEL_ERR_PLAN if there is none.  Never silently reads a stale buffer. */
