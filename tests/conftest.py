@@ -10,7 +10,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / on the GPU box)")
     config.addinivalue_line("markers", "gpu_extra: GPU robustness tests beyond the parity rows of SURVEY.md 8 (more bindings, more aspect ratios, more models of a "
                                        "property another parametrisation already covers): NOT selected by `-m gpu` -- the driver's GPU step has a time limit of 1200 s (round 6: `-m gpu` 420 tests in 849-924 s by box, "
-                                       "`-m gpu_extra` 16 tests in 277 s) --, run them with `-m gpu_extra` (or `-m \"gpu or gpu_extra\"`)")
+                                       "`-m gpu_extra` 16 tests in 282 s) --, run them with `-m gpu_extra` (or `-m \"gpu or gpu_extra\"`)")
 
 
 _TEST_TUNE = os.path.join(os.path.dirname(__file__), "golden", "gfx950_tests.tune")
